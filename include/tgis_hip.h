@@ -1,0 +1,173 @@
+/*
+ * tgis_hip.h — C ABI of libtgis_hip.so, the MI355X (gfx950) native-kernel library that sits
+ * where the reference's CUDA extension modules sit on the batched-decode hot path.
+ *
+ * Boundary: SURVEY.md §8(b) row #5.  The reference calls pybind/torch-extension functions with
+ * at::Tensor arguments (flash_attn_2_cuda, dropout_layer_norm, rotary_emb, exllamav2_kernels);
+ * this library exposes the same operations behind a plain C ABI: raw device pointers, int64
+ * sizes/strides, float scalars and a hipStream_t passed as void*.  No torch types, no allocation
+ * inside any call (callers pass workspaces; *_workspace_bytes queries say how large), no implicit
+ * synchronisation.  Every function returns 0 on success or a negative TGIS_E* code;
+ * tgis_last_error() returns a thread-local message for the last failure.
+ *
+ * dtype codes: TGIS_F16 (IEEE half) and TGIS_BF16.  All "T*" pointers below are 2-byte elements
+ * of that dtype.  All pointers are device pointers unless the comment says host.
+ *
+ * Reference citations are relative to /root/reference/server/text_generation_server/.
+ */
+#ifndef TGIS_HIP_H
+#define TGIS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGIS_OK 0
+#define TGIS_EINVAL (-1)   /* bad argument (shape, alignment, dtype) */
+#define TGIS_EHIP (-2)     /* a HIP runtime call failed */
+#define TGIS_EUNSUPPORTED (-3)
+#define TGIS_ENOMEM (-4)
+
+#define TGIS_F16 0
+#define TGIS_BF16 1
+
+/* KV page geometry: 32 tokens per page; per (page, k|v, kv_head) one
+ * 32*head_dim element block in an MFMA-fragment-ready order. */
+#define TGIS_KV_PAGE_TOKENS 32
+
+/* ---- library info ------------------------------------------------------------------------- */
+const char* tgis_version(void);          /* "tgis_hip x.y (gfx950)" */
+const char* tgis_arch(void);             /* offload arch the kernels were compiled for */
+const char* tgis_last_error(void);       /* thread-local, never NULL */
+int tgis_device_info(int device, int* num_cus, int64_t* hbm_bytes, char* name, int name_len);
+
+/* Optional per-op device timing with HIP events recorded on the op's own stream.
+ * tgis_timing_enable(1) makes every timed op (see TGIS_OP_*) bracket its kernel launch(es) with an
+ * event pair; tgis_timing_read() synchronises those events and returns count and total
+ * milliseconds since the last tgis_timing_reset().  Disabled by default (no events, no cost). */
+#define TGIS_OP_GPTQ_GEMM 0
+#define TGIS_OP_ATTN 1
+#define TGIS_OP_DENSE_GEMM 2
+#define TGIS_OP_NORM 3
+#define TGIS_OP_ROPE_KV 4
+#define TGIS_OP_ACT 5
+#define TGIS_OP_SAMPLE 6
+#define TGIS_OP_COUNT 7
+int tgis_timing_enable(int on);
+int tgis_timing_reset(void);
+int tgis_timing_read(int op, int64_t* count, double* total_ms);
+
+/* ---- GPTQ int4 linear (replaces exllamav2_kernels.make_q_matrix / gemm_half_q_half,
+ *      utils/gptq/exllamav2.py:14-62,100-144; normative arithmetic utils/gptq/quant_linear.py:130-192) */
+
+/* Bytes of the prepared (repacked) weight image for a [K,N] 4-bit matrix with `groups` groups. */
+int64_t tgis_gptq_prepared_bytes(int64_t K, int64_t N, int64_t groups);
+
+/* Repack GPTQ tensors into the kernel layout.  One-time, at load
+ * (the reference does this in Ex4bitLinearV2.post_init, exllamav2.py:124-137).
+ *   qweight [K/8, N] int32, qzeros [groups, N/8] int32, scales [groups, N] f16,
+ *   g_idx [K] int32 or NULL (NULL = trivial k / groupsize), perm_out [K] int32 or NULL:
+ *   when g_idx is not the trivial map (act-order) perm_out receives the row permutation that the
+ *   activation must be gathered with (x'[:,k'] = x[:,perm[k']]); groupsize = K / groups.
+ *   prepared: caller-owned buffer of tgis_gptq_prepared_bytes().  Requires K%32==0, N%32==0
+ *   (same asserts as exllamav2.py:118-119) and (K/groups)%16==0. */
+int tgis_gptq_prepare(const int32_t* qweight, const int32_t* qzeros, const void* scales,
+                      const int32_t* g_idx_host, int32_t* perm_out, int64_t K, int64_t N,
+                      int64_t groups, void* prepared, void* stream);
+
+/* Workspace for split-K partial sums + arrival counters of one gemm call. The counter region
+ * (first 4096 bytes) must be zero before the first call; the kernel leaves it zero. */
+int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
+
+/* out[M,N] f16 = x[M,K] f16 @ dequant(W)[K,N] (+ bias[N] f16 if non-NULL); fp32 accumulate.
+ * Fused int4-dequant MFMA kernel for any M (rows are processed in slabs of 32).
+ * x row stride ldx, out row stride ldo (elements).  perm (int32 [K] or NULL) gathers x columns
+ * for act-order matrices.  act: 0 = none, 1 = x is [M,2K] and the kernel consumes
+ * silu(x[:, :K]) * x[:, K:]  (fuses LlamaMLP's activation, flash_llama_modeling.py:332-335). */
+int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepared, const void* bias,
+                       const int32_t* perm, void* out, int64_t ldo, int64_t M, int64_t K, int64_t N,
+                       int64_t groups, int act, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Full dequantisation to a dense f16 [K,N] matrix (row-major), the "temp_dq" path the reference
+ * uses for M > 50 before a library GEMM (exllamav2.py:65-66,87). */
+int tgis_gptq_dequant_f16(const void* prepared, void* w_out, int64_t K, int64_t N, int64_t groups,
+                          void* stream);
+
+/* ---- dense skinny GEMM (replaces F.linear / torch.mm at decode sizes, utils/layers.py:110-111,
+ *      lm_head utils/layers.py:261) -------------------------------------------------------------- */
+int64_t tgis_dense_prepared_bytes(int64_t N, int64_t K);
+/* Repack a torch-Linear weight W[N,K] (row-major, dtype) into 32-column MFMA tiles. */
+int tgis_dense_prepare(const void* w, int64_t N, int64_t K, int dtype, void* prepared, void* stream);
+int64_t tgis_dense_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
+/* out[M,N] = x[M,K] @ W^T (+bias).  out_f32 != 0 writes float32 output (logits). */
+int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared, const void* bias, void* out,
+                    int64_t ldo, int64_t M, int64_t K, int64_t N, int dtype, int out_f32, int act,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- fused residual-add + RMSNorm / LayerNorm (replaces dropout_layer_norm.dropout_add_ln_fwd,
+ *      custom_modeling/flash_llama_modeling.py:132-152, utils/layers.py:376-396) ---------------- */
+/* res_out = x (+ residual); y = res_out * rsqrt(mean(res_out^2) + eps) * weight.
+ * residual may be NULL (first layer).  res_out may alias residual or x.  fp32 statistics. */
+int tgis_rmsnorm_residual(const void* x, const void* residual, const void* weight, void* y,
+                          void* res_out, int64_t rows, int64_t hidden, float eps, int dtype,
+                          void* stream);
+int tgis_layernorm_residual(const void* x, const void* residual, const void* weight, const void* bias,
+                            void* y, void* res_out, int64_t rows, int64_t hidden, float eps,
+                            int dtype, void* stream);
+
+/* ---- RoPE + KV-cache write (replaces rotary_emb.apply_rotary + the index_put at
+ *      flash_llama_modeling.py:262-268,282; utils/layers.py:466-472) ---------------------------- */
+/* qkv [T, (H + 2*Hkv)*D] (row stride ld_qkv): rotates q heads and k heads in place with the
+ * half-split (NeoX) rotation using cos/sin tables [max_pos, rot_dim/2] of the model dtype gathered by
+ * positions[T] (int32), then writes k and v of token t into KV page slot slots[t]
+ * (= page_id*32 + offset).  cos == NULL skips the rotation (learned-position models).
+ * k_pool / v_pool: this layer's K and V page pools, [num_pages][Hkv][32*D] each. */
+int tgis_rope_kv_write(void* qkv, int64_t ld_qkv, const void* cos, const void* sin,
+                       const int32_t* positions, const int32_t* slots, void* k_pool, void* v_pool,
+                       int64_t T, int H, int Hkv, int D, int rot_dim, int dtype, void* stream);
+
+/* ---- paged attention, prefill and decode (replaces flash_attn_2_cuda.varlen_fwd,
+ *      utils/flash_attn.py:43-78) ---------------------------------------------------------------- */
+/* Number of key-range splits the launcher will use for this shape (so callers can size workspace). */
+int tgis_attn_num_splits(int64_t B, int Hkv, int H, int64_t max_q_len, int64_t max_ctx);
+int64_t tgis_attn_workspace_bytes(int64_t total_q_tokens, int H, int D, int num_splits);
+/* Causal softmax(q k^T * scale) v over the paged cache.
+ *   q: [total_q, H, D] with token stride ld_q (elements); out: [total_q, H*D] contiguous.
+ *   cu_seqlens_q [B+1] int32: q token offsets per sequence (decode: arange).
+ *   ctx_lens [B] int32: tokens of each sequence present in the cache INCLUDING the q tokens.
+ *   block_tables [B, max_pages] int32: page ids.  q token i of sequence b sits at position
+ *   ctx_lens[b] - q_len_b + i and attends to cache positions <= its own.
+ *   max_q_len / max_ctx are launch-shape bounds (host ints). */
+int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, const void* v_pool,
+                    const int32_t* block_tables, int64_t max_pages, const int32_t* ctx_lens,
+                    const int32_t* cu_seqlens_q, void* out, int64_t B, int H, int Hkv, int D,
+                    int64_t max_q_len, int64_t max_ctx, float scale, int dtype, int num_splits,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- elementwise --------------------------------------------------------------------------------- */
+/* out[T,I] = act(gate_up[T,0:I]) * gate_up[T,I:2I]; act 1 = SiLU (flash_llama_modeling.py:332-335). */
+int tgis_act_mul(const void* gate_up, void* out, int64_t T, int64_t I, int act, int dtype, void* stream);
+/* out[T,I] = gelu(x) ; approx 1 = tanh (flash_santacoder_modeling.py:303-307). */
+int tgis_gelu(const void* x, void* out, int64_t n, int tanh_approx, int dtype, void* stream);
+/* out[T,E] = table[ids[T]] (+ pos_table[positions[T]] if non-NULL); ids int64. Out-of-range id -> 0 row
+ * (TensorParallelEmbedding's null row, utils/layers.py:325-357); ids are offset by -id_offset first. */
+int tgis_embedding(const int64_t* ids, const void* table, const int32_t* positions,
+                   const void* pos_table, void* out, int64_t T, int64_t E, int64_t vocab_rows,
+                   int64_t id_offset, int dtype, void* stream);
+/* Decode-step bookkeeping in one launch (flash_causal_lm.py:457-458,499 on device):
+ * positions[b] (int32) -> slots[b] = block_tables[b][pos/32]*32 + pos%32 ; ctx_lens[b] = pos+1. */
+int tgis_decode_slots(const int32_t* positions, const int32_t* block_tables, int64_t max_pages,
+                      int32_t* slots, int32_t* ctx_lens, int64_t B, void* stream);
+
+/* ---- greedy sampling (Greedy + log_softmax + gather, utils/tokens.py:44-46,238-271,388-397) ------ */
+/* Per row: token = argmax (lowest id on ties), logprob = logit[token] - logsumexp(row).
+ * logits [B,V] f32 (logits_f32 != 0) or model dtype. ids_out int64 [B], logprob_out f32 [B]. */
+int tgis_argmax_logprob(const void* logits, int64_t ld, int64_t B, int64_t V, int logits_f32, int dtype,
+                        int64_t* ids_out, float* logprob_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGIS_HIP_H */

@@ -1,0 +1,288 @@
+"""-m gpu: every HIP operator, called through the C ABI (tgis_amd.native -> libtgis_hip.so), against the
+CPU oracle (oracle/ops_ref.py) on the same seeded inputs.  Tolerances are stated per test: outputs are
+f16/bf16 roundings of fp32-accumulated results, so the bound is a few ulps of the output dtype relative to
+the magnitude of the result (integer outputs — token ids, slots — are compared bit-exact)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat(gpu_device):
+    from tgis_amd import native
+
+    native.load_library()
+    return native
+
+
+def _close(got, want, rtol, atol, what=""):
+    got = got.float().cpu()
+    want = want.float().cpu()
+    err = (got - want).abs()
+    bound = atol + rtol * want.abs()
+    bad = err > bound
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max err {err.max():.4g} " \
+                          f"(want max {want.abs().max():.4g})"
+
+
+# ---- GPTQ -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N,gs,act_order", [
+    (32, 4096, 4096, 128, False),      # o_proj, cfg3
+    (32, 4096, 12288, 128, False),     # fused qkv
+    (32, 11008, 4096, 128, False),     # down_proj (K not a power of two)
+    (1, 256, 64, 64, False),           # minimum sizes, single row
+    (7, 512, 96, 32, False),           # group size 32: scale-in-weight path
+    (33, 1024, 160, 128, False),       # two row slabs, ragged last slab
+    (16, 1024, 256, 1024, False),      # per-channel (one group)
+    (5, 1024, 128, 128, True),         # act-order g_idx
+    (70, 2048, 2752, 128, False),      # TP-shard width (22016/8), M > 64
+])
+def test_gptq_gemm(nat, gpu_device, M, K, N, gs, act_order):
+    qw, qz, sc, gi = ops_ref.make_gptq_tensors(K, N, gs, seed=K + N + M, act_order=act_order)
+    g = torch.Generator().manual_seed(M * 7 + 1)
+    x = (torch.randn(M, K, generator=g) * 0.5).half()
+    bias = (torch.randn(N, generator=g) * 0.1).half()
+    want = ops_ref.gptq_linear(x, qw, qz, sc, gi, gs, bias)
+    w = nat.GptqWeight(torch.from_numpy(qw).to(gpu_device), torch.from_numpy(qz).to(gpu_device),
+                       torch.from_numpy(sc).to(gpu_device), torch.from_numpy(gi), 4, gs)
+    ws = nat.Workspace(w.workspace_bytes(M), gpu_device)
+    got = nat.gptq_gemm(x.to(gpu_device), w, ws, bias=bias.to(gpu_device))
+    # f16 output of an fp32-accumulated sum of K terms: 2 ulp(f16) of the result + accumulated-order noise
+    _close(got, want, rtol=2e-3, atol=2e-3 * float(want.abs().mean()) + 1e-4, what="gptq_gemm")
+    # second call reuses workspace (arrival counters must have been left at zero)
+    got2 = nat.gptq_gemm(x.to(gpu_device), w, ws, bias=bias.to(gpu_device))
+    assert torch.equal(got, got2), "gptq_gemm is not deterministic / counters not reset"
+    # the full-dequant path must reproduce the formula bit-for-bit up to the f16 rounding of W
+    wd = nat.gptq_dequant(w).float().cpu()
+    wref = ops_ref.gptq_dequant(qw, qz, sc, gi, gs)
+    if act_order:
+        wref = wref[w.perm.cpu().long()]
+    assert torch.equal(wd, wref.half().float()), "gptq_dequant differs from the reference formula"
+
+
+def test_gptq_gemm_fused_silu(nat, gpu_device):
+    M, K, N, gs = 32, 1024, 512, 128
+    qw, qz, sc, gi = ops_ref.make_gptq_tensors(K, N, gs, seed=5)
+    g = torch.Generator().manual_seed(3)
+    gu = torch.randn(M, 2 * K, generator=g).half()
+    act = (torch.nn.functional.silu(gu[:, :K].float()).half().float() * gu[:, K:].float()).half()
+    want = ops_ref.gptq_linear(act, qw, qz, sc, gi, gs)
+    w = nat.GptqWeight(torch.from_numpy(qw).to(gpu_device), torch.from_numpy(qz).to(gpu_device),
+                       torch.from_numpy(sc).to(gpu_device), None, 4, gs)
+    ws = nat.Workspace(w.workspace_bytes(M), gpu_device)
+    got = nat.gptq_gemm(gu.to(gpu_device), w, ws, act=1)
+    _close(got, want, rtol=3e-3, atol=3e-3 * float(want.abs().mean()) + 1e-4, what="gptq_gemm+silu")
+
+
+# ---- dense skinny GEMM -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N,f32out", [(32, 4096, 32000, True), (16, 2048, 2560, False), (3, 200, 72, False),
+                                         (40, 512, 100, True)])
+def test_dense_gemm(nat, gpu_device, dtype, M, K, N, f32out):
+    g = torch.Generator().manual_seed(M + K + N)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(dtype)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype)
+    want = x.float() @ w.float().t()
+    if K % 8:
+        pytest.skip("x rows must be 16-byte aligned")
+    dw = nat.DenseWeight(w.to(gpu_device))
+    ws = nat.Workspace(dw.workspace_bytes(M), gpu_device)
+    got = nat.dense_gemm(x.to(gpu_device), dw, ws, out_f32=f32out)
+    eps = 1e-5 if f32out else (1e-3 if dtype == torch.float16 else 8e-3)
+    _close(got, want, rtol=2 * eps, atol=2 * eps * float(want.abs().mean()) + 1e-5, what="dense_gemm")
+
+
+# ---- norms ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,hidden", [(32, 4096), (1, 64), (5, 2048), (3, 8192)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_rmsnorm(nat, gpu_device, dtype, rows, hidden, with_res):
+    g = torch.Generator().manual_seed(rows + hidden)
+    x = torch.randn(rows, hidden, generator=g).to(dtype)
+    r = torch.randn(rows, hidden, generator=g).to(dtype) if with_res else None
+    w = (1 + 0.1 * torch.randn(hidden, generator=g)).to(dtype)
+    wy, wres = ops_ref.rmsnorm_residual(x, r, w, 1e-5)
+    y, res = nat.rmsnorm_residual(x.to(gpu_device), None if r is None else r.to(gpu_device), w.to(gpu_device), 1e-5)
+    ulp = 1e-3 if dtype == torch.float16 else 8e-3
+    _close(y, wy, rtol=ulp, atol=ulp, what="rmsnorm y")
+    assert torch.equal(res.cpu(), wres.to(dtype)), "residual stream must be the rounded fp32 sum, bit-exact"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_layernorm(nat, gpu_device, dtype):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(9, 6144, generator=g).to(dtype)
+    r = torch.randn(9, 6144, generator=g).to(dtype)
+    w = (1 + 0.1 * torch.randn(6144, generator=g)).to(dtype)
+    b = (0.1 * torch.randn(6144, generator=g)).to(dtype)
+    wy, wres = ops_ref.layernorm_residual(x, r, w, b, 1e-5)
+    y, res = nat.layernorm_residual(x.to(gpu_device), r.to(gpu_device), w.to(gpu_device), b.to(gpu_device), 1e-5)
+    ulp = 1e-3 if dtype == torch.float16 else 8e-3
+    _close(y, wy, rtol=ulp, atol=ulp, what="layernorm y")
+    assert torch.equal(res.cpu(), wres.to(dtype))
+
+
+# ---- RoPE + KV write + paged attention -------------------------------------------------------------------------
+def _paged_setup(gpu_device, dtype, lens_ctx, lens_q, H, Hkv, D, seed, num_pages_extra=3):
+    """Build q/k/v for sequences with ctx tokens of which the last q_len are 'new', scatter the whole
+    context into a shuffled page pool through tgis_rope_kv_write, return everything needed."""
+    g = torch.Generator().manual_seed(seed)
+    B = len(lens_ctx)
+    pages_per = [(c + 31) // 32 for c in lens_ctx]
+    total_pages = sum(pages_per) + num_pages_extra
+    perm = torch.randperm(total_pages, generator=g).tolist()
+    max_pages = max(pages_per)
+    bt = torch.zeros((B, max_pages), dtype=torch.int32)
+    pi = 0
+    for b in range(B):
+        for j in range(pages_per[b]):
+            bt[b, j] = perm[pi]
+            pi += 1
+    return B, bt, total_pages, max_pages, g
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("H,Hkv,D", [(32, 32, 128), (32, 4, 64), (8, 1, 128), (12, 1, 128), (48, 1, 128), (6, 2, 64)])
+def test_rope_kv_attention_prefill_then_decode(nat, gpu_device, dtype, H, Hkv, D):
+    """Prefill (ragged lengths incl. 1 and non-multiples of 32) then one decode step, against the oracle's
+    rotary + varlen attention.  Also checks the cache contents bit-exactly against the rotated k / v."""
+    lens = [45, 1, 32, 97, 64]
+    B, bt, total_pages, max_pages, g = _paged_setup(gpu_device, dtype, [l + 1 for l in lens], lens, H, Hkv, D, seed=H * D)
+    T = sum(lens)
+    W = (H + 2 * Hkv) * D
+    qkv = (torch.randn(T, W, generator=g) * 0.7).to(dtype)
+    cos, sin = ops_ref.rope_tables(D, 10000.0, 256, dtype)
+    pos = torch.cat([torch.arange(l) for l in lens]).int()
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    slots = torch.cat([bt[b, torch.arange(l) // 32].long() * 32 + torch.arange(l) % 32 for b, l in enumerate(lens)]).int()
+    # oracle
+    q3 = qkv[:, :H * D].view(T, H, D)
+    k3 = qkv[:, H * D:(H + Hkv) * D].view(T, Hkv, D)
+    v3 = qkv[:, (H + Hkv) * D:].view(T, Hkv, D)
+    qr = ops_ref.apply_rope(q3, cos[pos.long()], sin[pos.long()]).to(dtype)
+    kr = ops_ref.apply_rope(k3, cos[pos.long()], sin[pos.long()]).to(dtype)
+    want = ops_ref.attention_varlen(qr, kr, v3, cu, cu, D ** -0.5)
+    # device
+    kpool = torch.zeros((total_pages, Hkv, 32 * D), dtype=dtype, device=gpu_device)
+    vpool = torch.zeros_like(kpool)
+    dq = qkv.to(gpu_device)
+    nat.rope_kv_write(dq, cos.to(gpu_device), sin.to(gpu_device), pos.to(gpu_device), slots.to(gpu_device), kpool,
+                      vpool, H, Hkv, D, D)
+    # rotation parity: one rounding of an fp32 result
+    ulp = 1e-3 if dtype == torch.float16 else 8e-3
+    _close(dq[:, :H * D].view(T, H, D), qr, rtol=ulp, atol=ulp, what="rope q")
+    # cache contents == rotated k (as produced on the device) and v, bit-exact, at the right slots
+    kdev = dq[:, H * D:(H + Hkv) * D].view(T, Hkv, D).cpu()
+    for b, l in enumerate(lens):
+        for j in range((l + 31) // 32):
+            K, V = ops_ref.kv_page_unpack(kpool.cpu(), vpool.cpu(), int(bt[b, j]), Hkv, D)
+            n = min(32, l - j * 32)
+            t0 = int(cu[b]) + j * 32
+            assert torch.equal(K[:n], kdev[t0:t0 + n]), "K page content"
+            assert torch.equal(V[:n], v3[t0:t0 + n]), "V page content"
+    out = torch.empty((T, H * D), dtype=dtype, device=gpu_device)
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    nat.attn_paged(dq, dq.stride(0), kpool, vpool, bt.to(gpu_device), ctx.to(gpu_device), cu.to(gpu_device), out, B, H,
+                   Hkv, D, max(lens), max(lens), D ** -0.5, 1, None)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    _close(out.view(T, H, D), want, rtol=tol, atol=tol, what="prefill attention")
+
+    # ---- one decode step: a new token per sequence at position len ----------------------------------------
+    qkv1 = (torch.randn(B, W, generator=g) * 0.7).to(dtype)
+    pos1 = torch.tensor(lens, dtype=torch.int32)
+    slots1 = torch.empty(B, dtype=torch.int32, device=gpu_device)
+    ctx1 = torch.empty(B, dtype=torch.int32, device=gpu_device)
+    nat.decode_slots(pos1.to(gpu_device), bt.to(gpu_device), slots1, ctx1)
+    want_slots = torch.tensor([int(bt[b, l // 32]) * 32 + l % 32 for b, l in enumerate(lens)], dtype=torch.int32)
+    assert torch.equal(slots1.cpu(), want_slots) and torch.equal(ctx1.cpu(), pos1 + 1)
+    dq1 = qkv1.to(gpu_device)
+    nat.rope_kv_write(dq1, cos.to(gpu_device), sin.to(gpu_device), pos1.to(gpu_device), slots1, kpool, vpool, H, Hkv,
+                      D, D)
+    q1 = ops_ref.apply_rope(qkv1[:, :H * D].view(B, H, D), cos[pos1.long()], sin[pos1.long()]).to(dtype)
+    k1 = ops_ref.apply_rope(qkv1[:, H * D:(H + Hkv) * D].view(B, Hkv, D), cos[pos1.long()], sin[pos1.long()]).to(dtype)
+    v1 = qkv1[:, (H + Hkv) * D:].view(B, Hkv, D)
+    # full key set per sequence = prefill keys + the new one
+    ks, vs, cuk = [], [], [0]
+    for b, l in enumerate(lens):
+        ks += [kr[int(cu[b]):int(cu[b + 1])], k1[b:b + 1]]
+        vs += [v3[int(cu[b]):int(cu[b + 1])], v1[b:b + 1]]
+        cuk.append(cuk[-1] + l + 1)
+    want1 = ops_ref.attention_varlen(q1, torch.cat(ks), torch.cat(vs), torch.arange(B + 1), cuk, D ** -0.5)
+    cuq1 = torch.arange(B + 1, dtype=torch.int32, device=gpu_device)
+    for ns in (1, 2, 3):
+        out1 = torch.empty((B, H * D), dtype=dtype, device=gpu_device)
+        ws = nat.Workspace(nat.attn_workspace_bytes(B, H, D, ns), gpu_device)
+        nat.attn_paged(dq1, dq1.stride(0), kpool, vpool, bt.to(gpu_device), ctx1, cuq1, out1, B, H, Hkv, D, 1,
+                       max(lens) + 1, D ** -0.5, ns, ws)
+        _close(out1.view(B, H, D), want1, rtol=tol, atol=tol, what=f"decode attention splits={ns}")
+
+
+def test_attention_decode_long_context(nat, gpu_device):
+    """cfg3-shaped decode at reduced batch: ctx 1024..1040, MHA D=128, property check vs oracle."""
+    dtype, H, Hkv, D, B = torch.float16, 32, 32, 128, 3
+    lens = [1024, 1039, 1000]
+    g = torch.Generator().manual_seed(9)
+    pages_per = [(l + 31) // 32 for l in lens]
+    total_pages = sum(pages_per)
+    bt = torch.zeros((B, max(pages_per)), dtype=torch.int32)
+    perm = torch.randperm(total_pages, generator=g)
+    o = 0
+    for b in range(B):
+        bt[b, :pages_per[b]] = perm[o:o + pages_per[b]].int()
+        o += pages_per[b]
+    T = sum(lens)
+    kv = (torch.randn(T, 2 * Hkv * D, generator=g)).to(dtype)
+    dummy = torch.zeros((T, (H + 2 * Hkv) * D), dtype=dtype)
+    dummy[:, H * D:] = kv
+    slots = torch.cat([bt[b, torch.arange(l) // 32].long() * 32 + torch.arange(l) % 32 for b, l in enumerate(lens)]).int()
+    kpool = torch.zeros((total_pages, Hkv, 32 * D), dtype=dtype, device=gpu_device)
+    vpool = torch.zeros_like(kpool)
+    nat.rope_kv_write(dummy.to(gpu_device), None, None, None, slots.to(gpu_device), kpool, vpool, H, Hkv, D, D)
+    q = torch.randn(B, H * D, generator=g).to(dtype)
+    cu = [0] + list(np.cumsum(lens))
+    want = ops_ref.attention_varlen(q.view(B, H, D), kv[:, :Hkv * D].view(T, Hkv, D), kv[:, Hkv * D:].view(T, Hkv, D),
+                                    torch.arange(B + 1), cu, D ** -0.5)
+    out = torch.empty((B, H * D), dtype=dtype, device=gpu_device)
+    ns = nat.attn_num_splits(B, Hkv, H, 1, max(lens))
+    ws = nat.Workspace(nat.attn_workspace_bytes(B, H, D, ns), gpu_device)
+    nat.attn_paged(q.to(gpu_device), H * D, kpool, vpool, bt.to(gpu_device), torch.tensor(lens, dtype=torch.int32).to(gpu_device),
+                   torch.arange(B + 1, dtype=torch.int32, device=gpu_device), out, B, H, Hkv, D, 1, max(lens), D ** -0.5,
+                   ns, ws)
+    _close(out.view(B, H, D), want, rtol=2e-3, atol=2e-3, what="long decode attention")
+
+
+# ---- elementwise / sampling ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_act_mul_gelu_embedding(nat, gpu_device, dtype):
+    g = torch.Generator().manual_seed(2)
+    gu = torch.randn(7, 2 * 11008, generator=g).to(dtype)
+    got = nat.act_mul(gu.to(gpu_device), 11008)
+    ulp = 2e-3 if dtype == torch.float16 else 1.6e-2  # two roundings (act, product)
+    _close(got, ops_ref.silu_mul(gu, 11008), rtol=ulp, atol=1e-4, what="silu_mul")
+    x = torch.randn(5, 256, generator=g).to(dtype)
+    for tanh in (True, False):
+        _close(nat.gelu(x.to(gpu_device), tanh), ops_ref.gelu(x, tanh), rtol=ulp, atol=1e-3, what="gelu")
+    table = torch.randn(100, 64, generator=g).to(dtype)
+    ids = torch.tensor([3, 99, 0, 57, 120, -1], dtype=torch.int64)
+    got = nat.embedding(ids.to(gpu_device), table.to(gpu_device)).cpu()
+    want = torch.zeros(6, 64, dtype=dtype)
+    want[:4] = table[ids[:4]]
+    assert torch.equal(got, want), "embedding gather (out-of-shard ids give the null row)"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_argmax_logprob(nat, gpu_device, dtype):
+    g = torch.Generator().manual_seed(4)
+    logits = (torch.randn(32, 32000, generator=g) * 3).to(dtype)
+    logits[5, 100] = logits[5, 7] = logits[5].max() + 1  # tie: lowest index wins (tokens.py Greedy)
+    ids, lp = nat.argmax_logprob(logits.to(gpu_device))
+    wi, wl = ops_ref.greedy(logits)
+    assert torch.equal(ids.cpu(), wi), "greedy token ids must be bit-exact"
+    assert int(ids[5]) == 7
+    _close(lp, wl, rtol=1e-5, atol=1e-5, what="logprob")

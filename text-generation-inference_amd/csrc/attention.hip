@@ -1,0 +1,331 @@
+// Paged causal attention for prefill and decode on gfx950 (MFMA 16x16x32, wave64).
+// Replaces flash_attn_2_cuda.varlen_fwd as called from utils/flash_attn.py:43-78 for both call shapes of
+// custom_modeling/flash_llama_modeling.py:271-295 (prefill: causal over the fresh k/v; decode: q-len 1
+// over all cached slots) — here both read the paged cache that tgis_rope_kv_write has just filled.
+//
+// One workgroup = 4 waves handles one (sequence, kv head, 16-column q tile, key split).  The 16 MFMA
+// columns are (q token, q head of the GQA group) pairs, so one K/V stream serves the whole group.
+// Per 32-token page and wave:
+//   S^T[tok][col] = K[tok][:] . Q[col][:]      A = K fragment (1 KiB contiguous loads), B = Q^T
+//   online softmax per column: the column's statistics live in lane (l & 15) of every 16-lane row
+//   O^T[d][col]  += V^T[d][tok] . P^T[tok][col] A = V^T fragment (1 KiB contiguous loads), B = P^T
+// S^T's accumulator layout IS the B-operand layout of the second MFMA and O^T's column index is the
+// same lane, so the only cross-lane traffic per page is the 2-step row-max exchange.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+    const void* q;
+    int64_t ld_q;
+    const void* kpool;
+    const void* vpool;
+    const int32_t* bt;
+    int64_t max_pages;
+    const int32_t* ctx_lens;
+    const int32_t* cu_q;
+    void* out;
+    int H, Hkv, G, Gc, Gp, TQ, HC, NS;
+    float scale_log2;
+    float* ws_o;   // [total_q][H][NS][D]
+    float* ws_ml;  // [total_q][H][NS][2]
+};
+
+constexpr float NEG_BIG = -1.0e30f;
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_paged_kernel(AttnArgs a) {
+    using V8 = typename VecT<T>::x8;
+    constexpr int KS = D / 32;  // k-steps of the QK^T MFMA
+    constexpr int NB = D / 16;  // 16-row blocks of O^T
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int col = lane & 15, c = lane >> 4;
+    const int qt = blockIdx.x;
+    const int hk = blockIdx.y / a.HC, hc = blockIdx.y % a.HC;
+    const int b = blockIdx.z / a.NS, split = blockIdx.z % a.NS;
+
+    const int q0 = a.cu_q[b], q_len = a.cu_q[b + 1] - q0;
+    const int t0 = qt * a.TQ;
+    if (t0 >= q_len) return;
+    const int ctx = a.ctx_lens[b];
+    const int tq = col / a.Gp, g = col % a.Gp;
+    const int head = hk * a.G + hc * 16 + g;
+    const bool col_valid = (g < a.Gc) && (hc * 16 + g < a.G) && (t0 + tq < q_len);
+    // this column may attend to key positions < kmax
+    const int kmax = col_valid ? (ctx - q_len + t0 + tq + 1) : 0;
+    const int kend = ctx - q_len + min(q_len, t0 + a.TQ);  // keys needed by any column of the tile
+    const int pages = (kend + 31) >> 5;
+    const int pps = (pages + a.NS - 1) / a.NS;
+    const int pbeg = split * pps, pend = min(pages, pbeg + pps);
+
+    // Q^T fragments (B operand): lane supplies Q[col][ks*32 + c*8 .. +8]
+    V8 qf[KS];
+    {
+        const T* qp = reinterpret_cast<const T*>(a.q) + (int64_t)(q0 + t0 + tq) * a.ld_q + (int64_t)head * D + c * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (col_valid) {
+                qf[ks] = ld16<V8>(qp + ks * 32);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[ks][e] = (T)0.f;
+            }
+        }
+    }
+
+    f32x4 o[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) o[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = NEG_BIG, lsum = 0.f;
+
+    const int32_t* btrow = a.bt + (int64_t)b * a.max_pages;
+    int p = pbeg + w;
+    int pg = (p < pend) ? btrow[p] : 0;
+    for (; p < pend; p += 4) {
+        const int pg_next = (p + 4 < pend) ? btrow[p + 4] : 0;
+        const T* kb = reinterpret_cast<const T*>(a.kpool) + ((int64_t)pg * a.Hkv + hk) * (32 * D) + lane * 8;
+        const T* vb = reinterpret_cast<const T*>(a.vpool) + ((int64_t)pg * a.Hkv + hk) * (32 * D) + col * 32 + c * 8;
+        V8 kf[2][KS], vf[NB];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kf[t][ks] = __builtin_nontemporal_load(
+                reinterpret_cast<const V8*>(kb + t * (16 * D) + ks * 512));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) vf[nb] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(vb + nb * 512));
+
+        f32x4 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s[t] = mfma16(kf[t][ks], qf[ks], s[t]);
+        }
+        // scale, causal/length mask, tile max
+        float tmax = NEG_BIG;
+        const int kp0 = p * 32 + c * 4;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = s[t][r] * a.scale_log2;
+                v = (kp0 + t * 16 + r < kmax) ? v : NEG_BIG;
+                s[t][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);
+        const float alpha = exp2f(m - m_new);
+        m = m_new;
+        V8 pf;
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // masked entries contribute exactly 0 even while m is still NEG_BIG
+                float pv = (s[t][r] > 0.5f * NEG_BIG) ? exp2f(s[t][r] - m_new) : 0.f;
+                T pt = from_f32<T>(pv);
+                pf[t * 4 + r] = pt;
+                psum += to_f32(pt);  // normaliser from the rounded P, as flash-attention does
+            }
+        lsum = lsum * alpha + psum;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            o[nb] *= alpha;
+            o[nb] = mfma16(vf[nb], pf, o[nb]);
+        }
+        pg = pg_next;
+    }
+
+    // ---- combine the 4 waves through LDS ----------------------------------------------------------
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    float* so = reinterpret_cast<float*>(smem);          // [4][D][16]
+    float* sml = so + 4 * D * 16;                        // [4][2][16]
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) so[(w * D + nb * 16 + c * 4 + r) * 16 + col] = o[nb][r];
+    if (c == 0) {
+        sml[(w * 2 + 0) * 16 + col] = m;
+        sml[(w * 2 + 1) * 16 + col] = lsum;
+    }
+    __syncthreads();
+    // thread -> (column j, 8 consecutive d)
+    for (int item = tid; item < 16 * (D / 8); item += 256) {
+        const int j = item & 15, dc = item >> 4;
+        const int tqj = j / a.Gp, gj = j % a.Gp;
+        if (!(gj < a.Gc && hc * 16 + gj < a.G && t0 + tqj < q_len)) continue;
+        float mw[4], mstar = NEG_BIG;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mw[k] = sml[(k * 2) * 16 + j];
+            mstar = fmaxf(mstar, mw[k]);
+        }
+        float l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float f = exp2f(mw[k] - mstar);
+            l += sml[(k * 2 + 1) * 16 + j] * f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += so[(k * D + dc * 8 + e) * 16 + j] * f;
+        }
+        const int64_t tokidx = q0 + t0 + tqj;
+        const int headj = hk * a.G + hc * 16 + gj;
+        if (a.NS == 1) {
+            const float inv = l > 0.f ? 1.f / l : 0.f;
+            V8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(acc[e] * inv);
+            st16(reinterpret_cast<T*>(a.out) + (tokidx * a.H + headj) * D + dc * 8, ov);
+        } else {
+            float* wo = a.ws_o + ((tokidx * a.H + headj) * a.NS + split) * D + dc * 8;
+            *reinterpret_cast<f32x4*>(wo) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            *reinterpret_cast<f32x4*>(wo + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+            if (dc == 0) {
+                float* wm = a.ws_ml + ((tokidx * a.H + headj) * a.NS + split) * 2;
+                wm[0] = mstar;
+                wm[1] = l;
+            }
+        }
+    }
+}
+
+// out[tok][head][:] = sum_s O_s * 2^(m_s - m*) / sum_s l_s * 2^(m_s - m*);  one wave per (tok, head)
+template <typename T, int D>
+__global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restrict__ ws_o,
+                                                          const float* __restrict__ ws_ml, T* __restrict__ out,
+                                                          int NS) {
+    const int64_t th = blockIdx.x;  // tok*H + head
+    const int lane = threadIdx.x;
+    float mstar = NEG_BIG;
+    for (int s = 0; s < NS; ++s) mstar = fmaxf(mstar, ws_ml[(th * NS + s) * 2]);
+    float l = 0.f;
+    float acc[D / 64] = {};
+    for (int s = 0; s < NS; ++s) {
+        float f = exp2f(ws_ml[(th * NS + s) * 2] - mstar);
+        l += ws_ml[(th * NS + s) * 2 + 1] * f;
+#pragma unroll
+        for (int i = 0; i < D / 64; ++i) acc[i] += ws_o[(th * NS + s) * D + i * 64 + lane] * f;
+    }
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+    for (int i = 0; i < D / 64; ++i) out[th * D + i * 64 + lane] = from_f32<T>(acc[i] * inv);
+}
+
+static int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+struct AttnGeom {
+    int G, Gc, Gp, TQ, HC;
+};
+static AttnGeom geom(int H, int Hkv) {
+    AttnGeom g;
+    g.G = H / Hkv;
+    g.Gc = std::min(g.G, 16);
+    g.HC = (g.G + 15) / 16;
+    g.Gp = next_pow2(g.Gc);
+    g.TQ = 16 / g.Gp;
+    return g;
+}
+
+template <typename T, int D>
+static int launch_attn(const AttnArgs& a, dim3 grid, int64_t total_q, hipStream_t st) {
+    const size_t lds = (4 * D * 16 + 4 * 2 * 16) * sizeof(float);
+    hipLaunchKernelGGL((attn_paged_kernel<T, D>), grid, dim3(256), lds, st, a);
+    TGIS_CHECK_LAUNCH();
+    if (a.NS > 1) {
+        hipLaunchKernelGGL((attn_combine_kernel<T, D>), dim3((unsigned)(total_q * a.H)), dim3(64), 0, st, a.ws_o,
+                           a.ws_ml, (T*)a.out, a.NS);
+        TGIS_CHECK_LAUNCH();
+    }
+    return TGIS_OK;
+}
+
+}  // namespace
+
+extern "C" int tgis_attn_num_splits(int64_t B, int Hkv, int H, int64_t max_q_len, int64_t max_ctx) {
+    if (B <= 0 || Hkv <= 0 || H <= 0 || H % Hkv != 0 || max_q_len != 1) return 1;  // splits: decode only
+    AttnGeom g = geom(H, Hkv);
+    int64_t q_tiles = cdiv64(max_q_len, g.TQ);
+    int64_t base = B * Hkv * g.HC * q_tiles;
+    int64_t pages = cdiv64(std::max<int64_t>(max_ctx, 1), 32);
+    int64_t ns = cdiv64(1024, base);
+    ns = std::min<int64_t>(ns, cdiv64(pages, 4));  // at least one page per wave
+    ns = std::max<int64_t>(1, std::min<int64_t>(ns, 64));
+    return (int)ns;
+}
+
+extern "C" int64_t tgis_attn_workspace_bytes(int64_t total_q_tokens, int H, int D, int num_splits) {
+    if (num_splits <= 1) return 0;
+    return total_q_tokens * H * num_splits * ((int64_t)D + 2) * 4;
+}
+
+extern "C" int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, const void* v_pool,
+                               const int32_t* block_tables, int64_t max_pages, const int32_t* ctx_lens,
+                               const int32_t* cu_seqlens_q, void* out, int64_t B, int H, int Hkv, int D,
+                               int64_t max_q_len, int64_t max_ctx, float scale, int dtype, int num_splits,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+    TGIS_CHECK_ARG(q && k_pool && v_pool && block_tables && ctx_lens && cu_seqlens_q && out,
+                   "tgis_attn_paged: null tensor");
+    TGIS_CHECK_ARG(H > 0 && Hkv > 0 && H % Hkv == 0, "tgis_attn_paged: H (%d) must be a multiple of Hkv (%d)", H, Hkv);
+    TGIS_CHECK_ARG(D == 64 || D == 128, "tgis_attn_paged: head_dim %d not supported (64, 128)", D);
+    TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "tgis_attn_paged: bad dtype");
+    TGIS_CHECK_ARG(ld_q % 8 == 0 && ((uintptr_t)q % 16) == 0, "tgis_attn_paged: q must be 16-byte aligned");
+    TGIS_CHECK_ARG(max_q_len > 0 && max_pages > 0 && num_splits >= 1, "tgis_attn_paged: bad launch bounds");
+    TGIS_CHECK_ARG(num_splits == 1 || max_q_len == 1, "tgis_attn_paged: key splits are for decode (max_q_len == 1)");
+    (void)max_ctx;
+    if (B == 0) return TGIS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    AttnGeom g = geom(H, Hkv);
+    AttnArgs a;
+    a.q = q;
+    a.ld_q = ld_q;
+    a.kpool = k_pool;
+    a.vpool = v_pool;
+    a.bt = block_tables;
+    a.max_pages = max_pages;
+    a.ctx_lens = ctx_lens;
+    a.cu_q = cu_seqlens_q;
+    a.out = out;
+    a.H = H;
+    a.Hkv = Hkv;
+    a.G = g.G;
+    a.Gc = g.Gc;
+    a.Gp = g.Gp;
+    a.TQ = g.TQ;
+    a.HC = g.HC;
+    a.NS = num_splits;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    a.ws_o = nullptr;
+    a.ws_ml = nullptr;
+    int64_t total_q = 0;
+    if (num_splits > 1) {
+        // total q tokens is only needed to size the split workspace; callers pass B*max_q_len rows
+        total_q = B * max_q_len;
+        int64_t need = tgis_attn_workspace_bytes(total_q, H, D, num_splits);
+        TGIS_CHECK_ARG(workspace && workspace_bytes >= need, "tgis_attn_paged: workspace too small (%ld < %ld)",
+                       (long)workspace_bytes, (long)need);
+        a.ws_o = (float*)workspace;
+        a.ws_ml = a.ws_o + total_q * H * num_splits * D;
+    }
+    int64_t q_tiles = cdiv64(max_q_len, g.TQ);
+    TGIS_CHECK_ARG(q_tiles <= 2147483647LL && (int64_t)Hkv * g.HC <= 65535 && B * num_splits <= 65535,
+                   "tgis_attn_paged: grid too large");
+    dim3 grid((unsigned)q_tiles, (unsigned)(Hkv * g.HC), (unsigned)(B * num_splits));
+    TgisTimedScope timed(TGIS_OP_ATTN, st);
+    if (dtype == TGIS_F16) {
+        if (D == 128) return launch_attn<f16, 128>(a, grid, total_q, st);
+        return launch_attn<f16, 64>(a, grid, total_q, st);
+    } else {
+        if (D == 128) return launch_attn<bf16, 128>(a, grid, total_q, st);
+        return launch_attn<bf16, 64>(a, grid, total_q, st);
+    }
+}

@@ -1,0 +1,94 @@
+// Shared helpers for the gfx950 kernels of libtgis_hip.so (CDNA4 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/tgis_hip.h"
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing (host) ---------------------------------------------------------------------
+void tgis_set_error(const char* fmt, ...);
+#define TGIS_CHECK_ARG(cond, ...)          \
+    do {                                   \
+        if (!(cond)) {                     \
+            tgis_set_error(__VA_ARGS__);   \
+            return TGIS_EINVAL;            \
+        }                                  \
+    } while (0)
+#define TGIS_CHECK_HIP(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            tgis_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                           __LINE__);                                                     \
+            return TGIS_EHIP;                                                             \
+        }                                                                                 \
+    } while (0)
+#define TGIS_CHECK_LAUNCH() TGIS_CHECK_HIP(hipGetLastError())
+
+// Optional event timing around an op's launches (see tgis_timing_* in tgis_hip.h).
+struct TgisTimedScope {
+    int op;
+    hipStream_t stream;
+    void* slot;
+    TgisTimedScope(int op, hipStream_t s);
+    ~TgisTimedScope();
+};
+
+// ---- dtype traits (device) ---------------------------------------------------------------------
+template <typename T> struct VecT;
+template <> struct VecT<f16> { using x2 = f16x2; using x4 = f16x4; using x8 = f16x8; };
+template <> struct VecT<bf16> { using x2 = bf16x2; using x4 = bf16x4; using x8 = bf16x8; };
+
+__device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// 16-byte global load/store of 8 two-byte elements.
+template <typename V> __device__ __forceinline__ V ld16(const void* p) {
+    return *reinterpret_cast<const V*>(p);
+}
+template <typename V> __device__ __forceinline__ void st16(void* p, V v) {
+    *reinterpret_cast<V*>(p) = v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,134 @@
+// Fused residual-add + RMSNorm / LayerNorm for gfx950.
+// Replaces dropout_layer_norm.dropout_add_ln_fwd as called with p=0 from
+// custom_modeling/flash_llama_modeling.py:132-152 (RMSNorm) and utils/layers.py:376-396 (LayerNorm):
+//   res = x (+ residual)  [sum formed in fp32, stored in the model dtype]
+//   y   = norm(res) * weight (+ bias)   [statistics in fp32 from the fp32 sum, one rounding at the end]
+// One 256-thread workgroup per row, 16-byte loads, row cached in registers (hidden <= 16384).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAXV = 8;  // 8 x (256 threads x 8 elems) = 16384 max hidden
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+template <typename T, bool RMS>
+__global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
+                                                  const T* __restrict__ weight, const T* __restrict__ bias,
+                                                  T* y, T* res_out, int hidden,
+                                                  float eps) {
+    using V8 = typename VecT<T>::x8;
+    __shared__ float sh[4];
+    const int64_t row = blockIdx.x;
+    const T* xr = x + row * hidden;
+    const T* rr = residual ? residual + row * hidden : nullptr;
+    float v[MAXV][8];
+    const int nchunk = hidden >> 3;  // hidden % 8 == 0
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) {
+        int c = threadIdx.x + it * NT;
+        if (c < nchunk) {
+            V8 a = ld16<V8>(xr + c * 8);
+            V8 o;
+            if (rr) {
+                V8 b = ld16<V8>(rr + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[it][e] = to_f32(a[e]) + to_f32(b[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[it][e] = to_f32(a[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = from_f32<T>(v[it][e]);
+                s1 += v[it][e];
+                s2 += v[it][e] * v[it][e];
+            }
+            if (res_out) st16(res_out + row * hidden + c * 8, o);
+        }
+    }
+    float mean = 0.f, rstd;
+    if (RMS) {
+        float tot = block_sum(s2, sh);
+        rstd = rsqrtf(tot / hidden + eps);
+    } else {
+        mean = block_sum(s1, sh) / hidden;
+        float d2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAXV; ++it) {
+            int c = threadIdx.x + it * NT;
+            if (c < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float d = v[it][e] - mean;
+                    d2 += d * d;
+                }
+            }
+        }
+        float var = block_sum(d2, sh) / hidden;
+        rstd = rsqrtf(var + eps);
+    }
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) {
+        int c = threadIdx.x + it * NT;
+        if (c < nchunk) {
+            V8 wv = ld16<V8>(weight + c * 8);
+            V8 o;
+            if (bias) {
+                V8 bv = ld16<V8>(bias + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    o[e] = from_f32<T>((v[it][e] - mean) * rstd * to_f32(wv[e]) + to_f32(bv[e]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = from_f32<T>((v[it][e] - mean) * rstd * to_f32(wv[e]));
+            }
+            st16(y + row * hidden + c * 8, o);
+        }
+    }
+}
+
+template <bool RMS>
+static int launch_norm(const void* x, const void* residual, const void* weight, const void* bias, void* y,
+                       void* res_out, int64_t rows, int64_t hidden, float eps, int dtype, void* stream) {
+    TGIS_CHECK_ARG(x && weight && y, "norm: null tensor");
+    TGIS_CHECK_ARG(hidden > 0 && hidden % 8 == 0 && hidden <= NT * 8 * MAXV,
+                   "norm: hidden (%ld) must be a multiple of 8 and <= %d", (long)hidden, NT * 8 * MAXV);
+    TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "norm: bad dtype");
+    if (rows == 0) return TGIS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    TgisTimedScope timed(TGIS_OP_NORM, st);
+    if (dtype == TGIS_F16)
+        hipLaunchKernelGGL((norm_kernel<f16, RMS>), dim3((unsigned)rows), dim3(NT), 0, st, (const f16*)x,
+                           (const f16*)residual, (const f16*)weight, (const f16*)bias, (f16*)y, (f16*)res_out,
+                           (int)hidden, eps);
+    else
+        hipLaunchKernelGGL((norm_kernel<bf16, RMS>), dim3((unsigned)rows), dim3(NT), 0, st, (const bf16*)x,
+                           (const bf16*)residual, (const bf16*)weight, (const bf16*)bias, (bf16*)y,
+                           (bf16*)res_out, (int)hidden, eps);
+    TGIS_CHECK_LAUNCH();
+    return TGIS_OK;
+}
+
+}  // namespace
+
+extern "C" int tgis_rmsnorm_residual(const void* x, const void* residual, const void* weight, void* y,
+                                     void* res_out, int64_t rows, int64_t hidden, float eps, int dtype,
+                                     void* stream) {
+    return launch_norm<true>(x, residual, weight, nullptr, y, res_out, rows, hidden, eps, dtype, stream);
+}
+
+extern "C" int tgis_layernorm_residual(const void* x, const void* residual, const void* weight,
+                                       const void* bias, void* y, void* res_out, int64_t rows, int64_t hidden,
+                                       float eps, int dtype, void* stream) {
+    return launch_norm<false>(x, residual, weight, bias, y, res_out, rows, hidden, eps, dtype, stream);
+}

@@ -1,0 +1,374 @@
+"""ctypes binding of libtgis_hip.so (include/tgis_hip.h) for torch tensors on an MI355X.
+
+This is the drop-in boundary #5 of SURVEY.md §8(b): where the reference imports CUDA extension modules
+(`flash_attn_2_cuda`, `dropout_layer_norm`, `rotary_emb`, `exllamav2_kernels`; utils/flash_attn.py:23,
+utils/layers.py:361,403-404, utils/gptq/exllamav2.py:7) this module loads one C-ABI shared library and
+passes raw device pointers, sizes and the current HIP stream.  There is no CPU or eager-torch fallback:
+if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtgis_hip.so")
+
+F16, BF16 = 0, 1
+KV_PAGE_TOKENS = 32
+
+OP_GPTQ_GEMM, OP_ATTN, OP_DENSE_GEMM, OP_NORM, OP_ROPE_KV, OP_ACT, OP_SAMPLE = range(7)
+
+_c_i64 = ctypes.c_int64
+_c_int = ctypes.c_int
+_c_f = ctypes.c_float
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol declared in include/tgis_hip.h
+SIGNATURES = {
+    "tgis_version": (ctypes.c_char_p, []),
+    "tgis_arch": (ctypes.c_char_p, []),
+    "tgis_last_error": (ctypes.c_char_p, []),
+    "tgis_device_info": (_c_int, [_c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64), ctypes.c_char_p, _c_int]),
+    "tgis_timing_enable": (_c_int, [_c_int]),
+    "tgis_timing_reset": (_c_int, []),
+    "tgis_timing_read": (_c_int, [_c_int, ctypes.POINTER(_c_i64), ctypes.POINTER(ctypes.c_double)]),
+    "tgis_gptq_prepared_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
+    "tgis_gptq_prepare": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _vp, _vp]),
+    "tgis_gptq_gemm_workspace_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
+    "tgis_gptq_gemm_f16": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64,
+                                    _c_int, _vp, _c_i64, _vp]),
+    "tgis_gptq_dequant_f16": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_i64, _vp]),
+    "tgis_dense_prepared_bytes": (_c_i64, [_c_i64, _c_i64]),
+    "tgis_dense_prepare": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _vp, _vp]),
+    "tgis_dense_gemm_workspace_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
+    "tgis_dense_gemm": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int,
+                                 _c_int, _vp, _c_i64, _vp]),
+    "tgis_rmsnorm_residual": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f, _c_int, _vp]),
+    "tgis_layernorm_residual": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f, _c_int, _vp]),
+    "tgis_rope_kv_write": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_int, _c_int, _c_int,
+                                    _c_int, _c_int, _vp]),
+    "tgis_attn_num_splits": (_c_int, [_c_i64, _c_int, _c_int, _c_i64, _c_i64]),
+    "tgis_attn_workspace_bytes": (_c_i64, [_c_i64, _c_int, _c_int, _c_int]),
+    "tgis_attn_paged": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_int, _c_int,
+                                 _c_int, _c_i64, _c_i64, _c_f, _c_int, _c_int, _vp, _c_i64, _vp]),
+    "tgis_act_mul": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_int, _c_int, _vp]),
+    "tgis_gelu": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _vp]),
+    "tgis_embedding": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _vp]),
+    "tgis_decode_slots": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp]),
+    "tgis_argmax_logprob": (_c_int, [_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class TgisHipError(RuntimeError):
+    pass
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """dlopen the C-ABI library and bind every declared symbol.  Needs no GPU (no compute is run)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise TgisHipError(
+            f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')"
+        )
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load_library().tgis_last_error().decode()
+        raise TgisHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float16:
+        return F16
+    if dt == torch.bfloat16:
+        return BF16
+    raise TgisHipError(f"unsupported dtype {dt} (float16 / bfloat16 only)")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise TgisHipError("tensor is not on the GPU: the HIP path has no CPU fallback")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def version() -> str:
+    return load_library().tgis_version().decode()
+
+
+def timing_enable(on: bool):
+    _check(load_library().tgis_timing_enable(int(on)), "tgis_timing_enable")
+
+
+def timing_reset():
+    _check(load_library().tgis_timing_reset(), "tgis_timing_reset")
+
+
+def timing_read(op: int):
+    c = _c_i64()
+    ms = ctypes.c_double()
+    _check(load_library().tgis_timing_read(op, ctypes.byref(c), ctypes.byref(ms)), "tgis_timing_read")
+    return c.value, ms.value
+
+
+# ---- workspaces ---------------------------------------------------------------------------------
+class Workspace:
+    """Zero-initialised scratch for split-K slabs / arrival counters and attention splits.
+
+    One per stream of work.  The first 4096 bytes hold the arrival counters that the GEMM kernels leave
+    at zero after every call, so the buffer is zeroed exactly once, at allocation."""
+
+    def __init__(self, nbytes: int, device):
+        self.buf = torch.zeros(max(int(nbytes), 4096), dtype=torch.uint8, device=device)
+
+    def ensure(self, nbytes: int):
+        if self.buf.numel() < nbytes:
+            self.buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.buf.device)
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+    @property
+    def nbytes(self):
+        return self.buf.numel()
+
+
+# ---- GPTQ ------------------------------------------------------------------------------------------
+class GptqWeight:
+    """Prepared (repacked) GPTQ matrix; owner of the device image. Mirrors the q_handle of
+    Ex4bitLinearV2.post_init (utils/gptq/exllamav2.py:124-137)."""
+
+    def __init__(self, qweight, qzeros, scales, g_idx, bits: int, groupsize: int):
+        if bits != 4:
+            raise TgisHipError("only 4-bit GPTQ is supported (exllamav2.py:105)")
+        lib = load_library()
+        self.K = qweight.shape[0] * 8
+        self.N = qweight.shape[1]
+        self.groups = qzeros.shape[0]
+        if self.K % 32 or self.N % 32:
+            raise TgisHipError("GPTQ height and width must be multiples of 32 (exllamav2.py:118-119)")
+        dev = qweight.device
+        nbytes = lib.tgis_gptq_prepared_bytes(self.K, self.N, self.groups)
+        self.image = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        qweight = qweight.contiguous()
+        qzeros = qzeros.contiguous()
+        scales = scales.to(torch.float16).contiguous()
+        self.perm = None
+        gi = None
+        perm_buf = None
+        if g_idx is not None:
+            gi = g_idx.to("cpu", torch.int32).contiguous()
+            perm_buf = torch.empty(self.K, dtype=torch.int32, device=dev)
+        _check(
+            lib.tgis_gptq_prepare(
+                _ptr(qweight), _ptr(qzeros), _ptr(scales), gi.data_ptr() if gi is not None else None,
+                _ptr(perm_buf), self.K, self.N, self.groups, _ptr(self.image), _stream()),
+            "tgis_gptq_prepare")
+        if gi is not None:
+            gs = self.K // self.groups
+            trivial = bool((gi == (torch.arange(self.K, dtype=torch.int32) // gs)).all())
+            if not trivial:
+                self.perm = perm_buf
+        torch.cuda.current_stream().synchronize()  # qweight/qzeros/scales may be freed by the caller
+
+    def workspace_bytes(self, M: int) -> int:
+        return load_library().tgis_gptq_gemm_workspace_bytes(M, self.K, self.N)
+
+
+def gptq_gemm(x: torch.Tensor, w: GptqWeight, ws: Workspace, bias=None, act: int = 0, out=None) -> torch.Tensor:
+    """out[M,N] = (act ? silu(x[:, :K]) * x[:, K:] : x) @ dequant(W) (+bias), f16."""
+    assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1
+    M = x.shape[0]
+    assert x.shape[1] == (2 * w.K if act else w.K), (x.shape, w.K, act)
+    if out is None:
+        out = torch.empty((M, w.N), dtype=torch.float16, device=x.device)
+    ws.ensure(w.workspace_bytes(M))
+    _check(
+        load_library().tgis_gptq_gemm_f16(_ptr(x), x.stride(0), _ptr(w.image), _ptr(bias), _ptr(w.perm), _ptr(out),
+                                          out.stride(0), M, w.K, w.N, w.groups, act, ws.ptr, ws.nbytes, _stream()),
+        "tgis_gptq_gemm_f16")
+    return out
+
+
+def gptq_dequant(w: GptqWeight) -> torch.Tensor:
+    """Dense f16 [K,N] (rows in the prepared order: permuted by w.perm for act-order matrices)."""
+    out = torch.empty((w.K, w.N), dtype=torch.float16, device=w.image.device)
+    _check(load_library().tgis_gptq_dequant_f16(_ptr(w.image), _ptr(out), w.K, w.N, w.groups, _stream()),
+           "tgis_gptq_dequant_f16")
+    return out
+
+
+# ---- dense ------------------------------------------------------------------------------------------
+class DenseWeight:
+    """torch-Linear weight [N,K] repacked into MFMA tile order."""
+
+    def __init__(self, weight: torch.Tensor):
+        lib = load_library()
+        assert weight.dim() == 2
+        self.N, self.K = weight.shape
+        self.dtype = weight.dtype
+        weight = weight.contiguous()
+        self.image = torch.empty(lib.tgis_dense_prepared_bytes(self.N, self.K), dtype=torch.uint8,
+                                 device=weight.device)
+        _check(lib.tgis_dense_prepare(_ptr(weight), self.N, self.K, dtype_code(weight.dtype), _ptr(self.image),
+                                      _stream()), "tgis_dense_prepare")
+        torch.cuda.current_stream().synchronize()
+
+    def workspace_bytes(self, M: int) -> int:
+        return load_library().tgis_dense_gemm_workspace_bytes(M, self.K, self.N)
+
+
+def dense_gemm(x: torch.Tensor, w: DenseWeight, ws: Workspace, bias=None, out_f32: bool = False, act: int = 0,
+               out=None) -> torch.Tensor:
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == w.dtype
+    M = x.shape[0]
+    assert x.shape[1] == (2 * w.K if act else w.K)
+    if out is None:
+        out = torch.empty((M, w.N), dtype=torch.float32 if out_f32 else w.dtype, device=x.device)
+    ws.ensure(w.workspace_bytes(M))
+    _check(
+        load_library().tgis_dense_gemm(_ptr(x), x.stride(0), _ptr(w.image), _ptr(bias), _ptr(out), out.stride(0), M,
+                                       w.K, w.N, dtype_code(w.dtype), int(out_f32), act, ws.ptr, ws.nbytes,
+                                       _stream()), "tgis_dense_gemm")
+    return out
+
+
+# ---- norms --------------------------------------------------------------------------------------------
+def rmsnorm_residual(x, residual, weight, eps: float, y=None, res_out=None):
+    """(y, res) = fused add + RMSNorm; mirrors LlamaRMSNorm.forward (flash_llama_modeling.py:113-152)."""
+    assert x.dim() == 2 and x.is_contiguous()
+    rows, hidden = x.shape
+    if y is None:
+        y = torch.empty_like(x)
+    if res_out is None:
+        res_out = torch.empty_like(x) if residual is not None else x
+    _check(
+        load_library().tgis_rmsnorm_residual(_ptr(x), _ptr(residual), _ptr(weight), _ptr(y),
+                                             _ptr(res_out) if residual is not None else None, rows, hidden,
+                                             float(eps), dtype_code(x.dtype), _stream()), "tgis_rmsnorm_residual")
+    return y, res_out
+
+
+def layernorm_residual(x, residual, weight, bias, eps: float, y=None, res_out=None):
+    """(y, res) = fused add + LayerNorm; mirrors FastLayerNorm.forward (utils/layers.py:363-396)."""
+    assert x.dim() == 2 and x.is_contiguous()
+    rows, hidden = x.shape
+    if y is None:
+        y = torch.empty_like(x)
+    if res_out is None:
+        res_out = torch.empty_like(x) if residual is not None else x
+    _check(
+        load_library().tgis_layernorm_residual(_ptr(x), _ptr(residual), _ptr(weight), _ptr(bias), _ptr(y),
+                                               _ptr(res_out) if residual is not None else None, rows, hidden,
+                                               float(eps), dtype_code(x.dtype), _stream()),
+        "tgis_layernorm_residual")
+    return y, res_out
+
+
+# ---- rope + kv write, attention --------------------------------------------------------------------------
+def rope_kv_write(qkv, cos, sin, positions, slots, k_pool, v_pool, H: int, Hkv: int, D: int, rot_dim: int):
+    assert qkv.dim() == 2 and qkv.stride(1) == 1
+    T = qkv.shape[0]
+    _check(
+        load_library().tgis_rope_kv_write(_ptr(qkv), qkv.stride(0), _ptr(cos), _ptr(sin), _ptr(positions),
+                                          _ptr(slots), _ptr(k_pool), _ptr(v_pool), T, H, Hkv, D, rot_dim,
+                                          dtype_code(qkv.dtype), _stream()), "tgis_rope_kv_write")
+
+
+def attn_num_splits(B: int, Hkv: int, H: int, max_q_len: int, max_ctx: int) -> int:
+    return load_library().tgis_attn_num_splits(B, Hkv, H, max_q_len, max_ctx)
+
+
+def attn_workspace_bytes(total_q: int, H: int, D: int, num_splits: int) -> int:
+    return load_library().tgis_attn_workspace_bytes(total_q, H, D, num_splits)
+
+
+def attn_paged(q, ld_q: int, k_pool, v_pool, block_tables, ctx_lens, cu_seqlens_q, out, B: int, H: int, Hkv: int,
+               D: int, max_q_len: int, max_ctx: int, scale: float, num_splits: int, ws: Optional[Workspace]):
+    """q is a (view into a) [T, *] activation whose row stride is ld_q elements; out [T, H*D]."""
+    assert block_tables.dtype == torch.int32 and ctx_lens.dtype == torch.int32 and cu_seqlens_q.dtype == torch.int32
+    assert block_tables.is_contiguous() and out.is_contiguous()
+    wptr, wbytes = (ws.ptr, ws.nbytes) if ws is not None else (None, 0)
+    _check(
+        load_library().tgis_attn_paged(_ptr(q), ld_q, _ptr(k_pool), _ptr(v_pool), _ptr(block_tables),
+                                       block_tables.shape[1], _ptr(ctx_lens), _ptr(cu_seqlens_q), _ptr(out), B, H,
+                                       Hkv, D, max_q_len, max_ctx, float(scale), dtype_code(q.dtype), num_splits,
+                                       wptr, wbytes, _stream()), "tgis_attn_paged")
+    return out
+
+
+# ---- elementwise / sampling ---------------------------------------------------------------------------------
+def act_mul(gate_up, I: int, out=None):
+    T = gate_up.shape[0]
+    assert gate_up.is_contiguous() and gate_up.shape[1] == 2 * I
+    if out is None:
+        out = torch.empty((T, I), dtype=gate_up.dtype, device=gate_up.device)
+    _check(load_library().tgis_act_mul(_ptr(gate_up), _ptr(out), T, I, 1, dtype_code(gate_up.dtype), _stream()),
+           "tgis_act_mul")
+    return out
+
+
+def gelu(x, tanh_approx: bool, out=None):
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    _check(load_library().tgis_gelu(_ptr(x), _ptr(out), x.numel(), int(tanh_approx), dtype_code(x.dtype), _stream()),
+           "tgis_gelu")
+    return out
+
+
+def embedding(ids, table, positions=None, pos_table=None, id_offset: int = 0, out=None):
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and table.is_contiguous()
+    T = ids.numel()
+    E = table.shape[1]
+    if out is None:
+        out = torch.empty((T, E), dtype=table.dtype, device=table.device)
+    _check(
+        load_library().tgis_embedding(_ptr(ids), _ptr(table), _ptr(positions), _ptr(pos_table), _ptr(out), T, E,
+                                      table.shape[0], id_offset, dtype_code(table.dtype), _stream()),
+        "tgis_embedding")
+    return out
+
+
+def decode_slots(positions, block_tables, slots, ctx_lens):
+    B = positions.numel()
+    _check(
+        load_library().tgis_decode_slots(_ptr(positions), _ptr(block_tables), block_tables.shape[1], _ptr(slots),
+                                         _ptr(ctx_lens), B, _stream()), "tgis_decode_slots")
+
+
+def argmax_logprob(logits, ids_out=None, logprob_out=None):
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    B, V = logits.shape
+    if ids_out is None:
+        ids_out = torch.empty(B, dtype=torch.int64, device=logits.device)
+    if logprob_out is None:
+        logprob_out = torch.empty(B, dtype=torch.float32, device=logits.device)
+    f32 = logits.dtype == torch.float32
+    _check(
+        load_library().tgis_argmax_logprob(_ptr(logits), logits.stride(0), B, V, int(f32),
+                                           0 if f32 else dtype_code(logits.dtype), _ptr(ids_out),
+                                           _ptr(logprob_out), _stream()), "tgis_argmax_logprob")
+    return ids_out, logprob_out
