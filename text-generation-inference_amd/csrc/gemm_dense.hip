@@ -46,7 +46,6 @@ struct DenseArgs {
     int M, K, N, KB, S, NT, KS;
     int out_f32;
     float* slabs;
-    unsigned* counters;
 };
 
 constexpr int DMAXSTEPS = 4;
@@ -170,33 +169,29 @@ __global__ __launch_bounds__(DTHREADS) void dense_gemm_kernel(DenseArgs a) {
             *reinterpret_cast<f32x4*>(a.slabs + (((int64_t)split * a.NT + nt2) << 10) + m * 32 + c4) = v;
         }
     }
-    if (a.S == 1) return;
+}
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    volatile int* s_last = reinterpret_cast<volatile int*>(smem);
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned t = __hip_atomic_fetch_add(a.counters + ntg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_last = (t == (unsigned)(a.S - 1));
-    }
-    __syncthreads();
-    if (!*s_last) return;
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(a.counters + ntg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    for (int o = tid; o < WN * 256; o += DTHREADS) {
-        int wn2 = o >> 8, m = (o >> 3) & 31, c4 = (o & 7) * 4;
-        int nt2 = ntg * WN + wn2;
-        if (nt2 >= a.NT || m >= a.M) continue;
-        f32x4 v = {0, 0, 0, 0};
-        for (int s2 = 0; s2 < a.S; ++s2)
-            v += __builtin_nontemporal_load(
-                reinterpret_cast<const f32x4*>(a.slabs + (((int64_t)s2 * a.NT + nt2) << 10) + m * 32 + c4));
-        emit(m, nt2 * 32 + c4, v);
+// Sum the S split-K slabs in fixed order and emit the output (+bias); thread = (row, 4 columns).
+template <typename T>
+__global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(DenseArgs a) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)a.NT * 256) return;
+    int c4 = (idx & 7) * 4, m = (idx >> 3) & 31;
+    int64_t nt = idx >> 8;
+    if (m >= a.M) return;
+    f32x4 v = {0, 0, 0, 0};
+    for (int s2 = 0; s2 < a.S; ++s2)
+        v += *reinterpret_cast<const f32x4*>(a.slabs + (((int64_t)s2 * a.NT + nt) << 10) + m * 32 + c4);
+    int64_t n = nt * 32 + c4;
+    for (int e = 0; e < 4; ++e) {
+        if (n + e < a.N) {
+            float f = v[e];
+            if (a.bias) f += to_f32(reinterpret_cast<const T*>(a.bias)[n + e]);
+            if (a.out_f32)
+                reinterpret_cast<float*>(a.out)[(int64_t)m * a.ldo + n + e] = f;
+            else
+                reinterpret_cast<T*>(a.out)[(int64_t)m * a.ldo + n + e] = from_f32<T>(f);
+        }
     }
 }
 
@@ -310,7 +305,6 @@ extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared,
     int64_t need = 4096 + (pl.S > 1 ? (int64_t)pl.S * NT * 4096 : 0);
     TGIS_CHECK_ARG(workspace && workspace_bytes >= need, "tgis_dense_gemm: workspace too small (%ld < %ld)",
                    (long)workspace_bytes, (long)need);
-    TGIS_CHECK_ARG(cdiv64(NT, pl.WN) <= 1024, "tgis_dense_gemm: N too large for the counter region");
     TgisTimedScope timed(TGIS_OP_DENSE_GEMM, st);
     DenseArgs a;
     a.prep = prepared;
@@ -324,7 +318,6 @@ extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared,
     a.NT = (int)NT;
     a.KS = (int)KS;
     a.out_f32 = out_f32;
-    a.counters = (unsigned*)workspace;
     a.slabs = (float*)((uint8_t*)workspace + 4096);
     dim3 grid((unsigned)cdiv64(NT, pl.WN), (unsigned)pl.S);
     const int64_t esz_out = out_f32 ? 4 : 2;
@@ -335,6 +328,13 @@ extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared,
         int rc = dtype == TGIS_F16 ? dispatch_dense<f16>(a, pl.WN, act, grid, pl.lds, st)
                                    : dispatch_dense<bf16>(a, pl.WN, act, grid, pl.lds, st);
         if (rc != TGIS_OK) return rc;
+        if (pl.S > 1) {
+            if (dtype == TGIS_F16)
+                hipLaunchKernelGGL(dense_splitk_reduce_kernel<f16>, dim3((unsigned)NT), dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL(dense_splitk_reduce_kernel<bf16>, dim3((unsigned)NT), dim3(256), 0, st, a);
+            TGIS_CHECK_LAUNCH();
+        }
     }
     return TGIS_OK;
 }

@@ -6,11 +6,12 @@
 // 184-194):  W[k,n] = (q[k,n] - (z[g(k),n] + 1)) * s[g(k),n];  y = x @ W, fp32 accumulate, f16 out.
 //
 // Prepared image, NT = ceil(N/32) column tiles, KS = ceil(K/64) k-steps, G groups:
-//   A: wq  [NT][KS][64 lanes][4] int32 — lane l word i = the 8 nibbles of rows
-//         k = (ks*8 + (l>>5)*4 + i)*8 .. +7 of column n = nt*32 + (l&31)   (1 KiB per wave load,
-//         and exactly the B-operand fragment of v_mfma_f32_32x32x16_f16: 8 consecutive k per lane)
-//   B: scl [NT][G][32] f16,   C: zp1 [NT][G][32] u8 (= z + 1, 1..16)
+//   A: wq [NT][KS][64 lanes][4] int32 — lane l word i = the 8 nibbles of rows
+//        k = (ks*8 + (l>>5)*4 + i)*8 + {0,2,4,6,1,3,5,7} of column n = nt*32 + (l&31): one KiB per wave
+//        load, and (after dequant8) exactly the B-operand fragment of v_mfma_f32_32x32x16_f16
+//   B: sz [NT][G][32] u32 = { scale f16 , (1024 + z + 1) f16 }
 // Rows are pre-permuted by the act-order permutation when g_idx is not trivial.
+#include <stdlib.h>
 #include <algorithm>
 #include <numeric>
 #include <vector>
@@ -19,18 +20,23 @@
 namespace {
 
 struct PrepLayout {
-    int64_t NT, KS, G, offB, offC, total;
+    int64_t NT, KS, G, offB, total;
 };
 static PrepLayout prep_layout(int64_t K, int64_t N, int64_t G) {
     PrepLayout p;
     p.NT = cdiv64(N, 32);
-    p.KS = cdiv64(K, 64);
+    // whole 256-row chunks (rows >= K hold zero nibbles; x is zero there) + one pad step so that the tile
+    // stride is not a multiple of 64 KiB: equal-phase waves would otherwise camp on the same HBM channels
+    p.KS = cdiv64(K, 256) * 4 + 1;
     p.G = G;
     p.offB = p.NT * p.KS * 1024;
-    p.offC = p.offB + p.NT * G * 64;
-    p.total = p.offC + p.NT * G * 32;
+    p.total = p.offB + p.NT * G * 128;
     p.total = (p.total + 255) & ~int64_t(255);
     return p;
+}
+
+__device__ __forceinline__ int nib_src(int j) {  // stored nibble j holds row offset {0,2,4,6,1,3,5,7}[j]
+    return (j < 4) ? 2 * j : 2 * (j - 4) + 1;
 }
 
 __global__ void gptq_prepare_w_kernel(const int32_t* __restrict__ qweight, const int32_t* __restrict__ perm,
@@ -47,13 +53,15 @@ __global__ void gptq_prepare_w_kernel(const int32_t* __restrict__ qweight, const
     uint32_t v = 0;
     if (n < N && p * 8 < K) {
         if (perm == nullptr) {
-            v = (uint32_t)qweight[p * N + n];
+            uint32_t w = (uint32_t)qweight[p * N + n];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v |= ((w >> (4 * nib_src(j))) & 15u) << (4 * j);
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                int64_t ksrc = perm[p * 8 + e];
+            for (int j = 0; j < 8; ++j) {
+                int64_t ksrc = perm[p * 8 + nib_src(j)];
                 uint32_t w = (uint32_t)qweight[(ksrc >> 3) * N + n];
-                v |= ((w >> (4 * (ksrc & 7))) & 15u) << (4 * e);
+                v |= ((w >> (4 * (ksrc & 7))) & 15u) << (4 * j);
             }
         }
     }
@@ -61,286 +69,277 @@ __global__ void gptq_prepare_w_kernel(const int32_t* __restrict__ qweight, const
 }
 
 __global__ void gptq_prepare_sz_kernel(const int32_t* __restrict__ qzeros, const f16* __restrict__ scales,
-                                       f16* __restrict__ scl, uint8_t* __restrict__ zp1, int64_t N,
-                                       int64_t NT, int64_t G) {
+                                       uint32_t* __restrict__ sz, int64_t N, int64_t NT, int64_t G) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= NT * G * 32) return;
     int c = idx & 31;
     int64_t g = (idx >> 5) % G;
     int64_t nt = (idx >> 5) / G;
     int64_t n = nt * 32 + c;
-    f16 s = (f16)0.f;
-    uint8_t z = 1;
+    f16x2 v = {(f16)0.f, (f16)1025.f};
     if (n < N) {
-        s = scales[g * N + n];
         uint32_t w = (uint32_t)qzeros[g * (N / 8) + (n >> 3)];
-        z = (uint8_t)(((w >> (4 * (n & 7))) & 15u) + 1u);
+        v[0] = scales[g * N + n];
+        v[1] = (f16)(float)(1024u + ((w >> (4 * (n & 7))) & 15u) + 1u);
     }
-    scl[idx] = s;
-    zp1[idx] = z;
+    sz[idx] = __builtin_bit_cast(uint32_t, v);
 }
 
-// 8 nibbles of q -> 8 halves (q_e - zp1) in the order [0,4,1,5,2,6,3,7] (exact integer arithmetic).
-__device__ __forceinline__ f16x8 dequant8(uint32_t q, f16x2 zc, f16x2 zd) {
-    const uint32_t M0 = 0x000F000Fu, M1 = 0x00F000F0u, EX = 0x64006400u;  // 0x6400 = 1024.0h
+// 8 nibbles of q -> 8 halves (q_j - zp1) * s.  The prepared image stores the nibbles of rows k0..k7 in the
+// order [k0,k2,k4,k6,k1,k3,k5,k7], so the four (low,high) pairs come out as (k0,k1),(k2,k3),(k4,k5),(k6,k7):
+// the natural k order of the MFMA B fragment.  (q - zp1) is exact integer arithmetic in f16 (|values| < 2048);
+// the product with the f16 scale is rounded once to f16, as in exllamav2's dequantisation.
+__device__ __forceinline__ uint32_t and_or(uint32_t q, uint32_t mask, uint32_t ex) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(q), "s"(mask), "v"(ex));
+    return r;
+}
+__device__ __forceinline__ f16x8 dequant8(uint32_t q, f16x2 zc, f16x2 zd, f16x2 sc, uint32_t EX, uint32_t M0,
+                                          uint32_t M1) {
+    // EX = 0x64006400 (1024.0h pair) lives in a VGPR and the masks in SGPRs: (q & mask) | EX is one VALU op
     const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
     uint32_t q2 = q >> 8;
-    uint32_t a0 = (q & M0) | EX;   // 1024 + n0 , 1024 + n4
-    uint32_t a1 = (q & M1) | EX;   // 1024 + 16 n1 , 1024 + 16 n5
-    uint32_t a2 = (q2 & M0) | EX;  // n2, n6
-    uint32_t a3 = (q2 & M1) | EX;  // n3, n7
-    f16x2 h0 = __builtin_bit_cast(f16x2, a0) - zc;
-    f16x2 h1 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, a1), r16, zd);
-    f16x2 h2 = __builtin_bit_cast(f16x2, a2) - zc;
-    f16x2 h3 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, a3), r16, zd);
-    f16x8 r;
-    r[0] = h0[0]; r[1] = h0[1]; r[2] = h1[0]; r[3] = h1[1];
-    r[4] = h2[0]; r[5] = h2[1]; r[6] = h3[0]; r[7] = h3[1];
-    return r;
+    uint32_t a0 = and_or(q, M0, EX);   // 1024 + n0 , 1024 + n4
+    uint32_t a1 = and_or(q, M1, EX);   // 1024 + 16 n1 , 1024 + 16 n5
+    uint32_t a2 = and_or(q2, M0, EX);  // n2, n6
+    uint32_t a3 = and_or(q2, M1, EX);  // n3, n7
+    f16x2 h0 = (__builtin_bit_cast(f16x2, a0) - zc) * sc;
+    f16x2 h1 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, a1), r16, zd) * sc;
+    f16x2 h2 = (__builtin_bit_cast(f16x2, a2) - zc) * sc;
+    f16x2 h3 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, a3), r16, zd) * sc;
+    u32x4 packed = {__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1),
+                    __builtin_bit_cast(uint32_t, h2), __builtin_bit_cast(uint32_t, h3)};
+    return __builtin_bit_cast(f16x8, packed);
 }
 
 struct GemmArgs {
     const f16* x;
     int64_t ldx;
     const uint8_t* prep;
-    int64_t offB, offC;
+    int64_t offB;
     const f16* bias;
     const int32_t* perm;
     f16* out;
     int64_t ldo;
-    int M, K, N;        // M = rows in this slab (<=32)
-    int G, gs;          // groups, group size
-    int KB;             // k-range per block (multiple of 64)
-    int S;              // global k splits
+    int M, K, N;   // M = all rows (grid.z walks 32-row slabs)
+    int G, gs;     // groups, group size
+    int KR;        // k-range per block (multiple of 256)
+    int S;         // global k splits
     int NT, KS;
-    float* slabs;       // [S][NT][32*32] f32
-    unsigned* counters; // [ceil(NT/WN)]
+    float* slabs;  // [Mslabs][S][32][NT*32] f32 partial sums (S > 1)
+    int dbg;       // tuning hook (TGIS_GPTQ_DBG): 1 = restage x chunk 0 only, 2 = reload weight step 0 only
 };
 
-constexpr int MAXSTEPS = 8;  // k64-steps per wave
-constexpr int GEMM_THREADS = 512;
+constexpr int KC = 256;     // k per LDS chunk (4 k64-steps)
+constexpr int RS = KC + 8;  // LDS row stride in halves (+16 B -> conflict-free ds_read_b128)
+constexpr int RING = 4;     // weight loads in flight per wave = one chunk ahead (4 KiB)
 
-// Block = 8 waves = WN column tiles x WK=8/WN k-parts over one [KB x 32*WN] rectangle of W; the
-// x slab [32][KB] (f16, optionally silu(gate)*up fused) is staged once in LDS in the nibble order.
-template <int WN, int ACT, bool GROUP_ACC>
-__global__ __launch_bounds__(GEMM_THREADS) void gptq_gemm_kernel(GemmArgs a) {
-    constexpr int WK = 8 / WN;
+// Streaming kernel: a block of WN waves owns 32*WN columns x [k0,k1) of W.  Each wave streams its own
+// 32-column tile (1 KiB per load, one chunk = 4 loads ahead) while the block double-buffers 32 x 256 chunks
+// of x through LDS.  The main loop is branch-free (clamped addresses + selects) so that hipcc keeps counted
+// vmcnt waits and the prefetched loads stay in flight across the per-chunk barrier.
+// GROUP64: group size is a multiple of 64 (one scale/zero per lane per step, prefetched with the weights).
+template <int WN, int ACT, bool GROUP64, bool PERM>
+__global__ __launch_bounds__(64 * WN) void gptq_gemm_kernel(GemmArgs a) {
+    constexpr int THREADS = 64 * WN;
+    constexpr int NJ = 1024 / THREADS;  // 16-byte x pieces per thread per chunk (32 rows x 32 pieces)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = tid >> 6;
-    const int wn = w % WN, wk = w / WN;
-    const int ntg = blockIdx.x, split = blockIdx.y;
-    const int kb0 = split * a.KB;
-    const int kb1 = min(a.K, kb0 + a.KB);
-    const int klen = kb1 - kb0;                   // >0 by construction
-    const int steps_total = (klen + 63) >> 6;
-    const int rs = a.KB + 8;                      // LDS row stride in halves (+16 B: conflict-free b128)
-    f16* xs = reinterpret_cast<f16*>(smem);
+    f16* xs = reinterpret_cast<f16*>(smem);  // [2][32][RS]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ntg = blockIdx.x, split = blockIdx.y, mslab = blockIdx.z;
+    const int m0 = mslab * 32;
+    const int mrows = min(32, a.M - m0);
+    const int k0 = split * a.KR;
+    const int k1 = min(a.K, k0 + a.KR);
+    const int nchunks = (k1 - k0 + KC - 1) / KC;       // >= 1
+    const int last_step = nchunks * 4 - 1;              // image is padded to whole chunks
+    const int nt_raw = ntg * WN + w;
+    const int nt = min(nt_raw, a.NT - 1);               // out-of-range waves recompute the last tile, never store
+    const int ks0 = k0 >> 6;
+    const int spg = a.G == 1 ? (1 << 30) : max(1, a.gs >> 6);  // k64-steps per group (GROUP64)
 
-    // ---- issue this wave's weight loads first (HBM latency overlaps the x staging) ------------
-    const int spw = (steps_total + WK - 1) / WK;
-    const int st0 = wk * spw;
-    const int nt = ntg * WN + wn;
-    const bool active = nt < a.NT;
-    const int nsteps = active ? max(0, min(spw, steps_total - st0)) : 0;
-    const int ks0 = (kb0 >> 6) + st0;
-    u32x4 wq[MAXSTEPS];
-    f16 sc[MAXSTEPS];
-    uint8_t zz[MAXSTEPS];
-    const u32x4* wbase = reinterpret_cast<const u32x4*>(a.prep) + ((int64_t)nt * a.KS + ks0) * 64 + lane;
-    const f16* sbase = reinterpret_cast<const f16*>(a.prep + a.offB) + (int64_t)nt * a.G * 32 + (lane & 31);
-    const uint8_t* zbase = a.prep + a.offC + (int64_t)nt * a.G * 32 + (lane & 31);
+    const u32x4* wptr = reinterpret_cast<const u32x4*>(a.prep) + ((int64_t)nt * a.KS + ks0) * 64 + lane;
+    const uint32_t* szp = reinterpret_cast<const uint32_t*>(a.prep + a.offB) + (int64_t)nt * a.G * 32 + (lane & 31);
+    auto sz_at = [&](int step) -> uint32_t {
+        int g = min((ks0 + step) / spg, a.G - 1);
+        return szp[g * 32];
+    };
+    u32x4 wq[RING];
+    uint32_t szr[RING];
 #pragma unroll
-    for (int s = 0; s < MAXSTEPS; ++s) {
-        if (s < nsteps) {
-            wq[s] = __builtin_nontemporal_load(wbase + s * 64);
-            if (GROUP_ACC) {
-                int g = ((ks0 + s) * 64) / a.gs;
-                sc[s] = sbase[g * 32];
-                zz[s] = zbase[g * 32];
-            }
-        }
+    for (int s = 0; s < RING; ++s) {
+        wq[s] = __builtin_nontemporal_load(wptr + s * 64);
+        if (GROUP64) szr[s] = sz_at(s);
     }
 
-    // ---- stage x[0:32, kb0:kb1] into LDS (zero-padded), 16 B per thread per iteration ---------
-    {
-        const int c8n = a.KB >> 3;  // 16-byte chunks per row
-        for (int idx = tid; idx < 32 * c8n; idx += GEMM_THREADS) {
-            int row = idx / c8n, c8 = idx - row * c8n;
-            int k = kb0 + c8 * 8;
-            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (row < a.M && k < kb1) {
-                const f16* xr = a.x + (int64_t)row * a.ldx;
-                if (a.perm == nullptr) {
-                    v = ld16<f16x8>(xr + k);
-                    if (ACT == 1) {
-                        f16x8 u = ld16<f16x8>(xr + a.K + k);
+    // ---- x staging: thread t handles rows (t / 32) + (THREADS/32) j, 16-byte column piece (t & 31) ----
+    const f16* xbase = a.x + (int64_t)m0 * a.ldx;
+    const int srow = tid >> 5, scol = (tid & 31) * 8;
+    constexpr int RSTEP = THREADS / 32;
+    f16x8 xg[NJ], xu[NJ];
+    bool xok[NJ];
+    auto stage_load = [&](int chunk) {
+        const int kk = k0 + chunk * KC + scol;
+        const bool kok = kk < k1;
+        const int kc = kok ? kk : 0;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            float gte = (float)v[e];
-                            float sl = gte / (1.f + __expf(-gte));
-                            // reference rounds silu(gate) to f16 before the multiply (eager torch ops)
-                            v[e] = (f16)((float)(f16)sl * (float)u[e]);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        int ksrc = a.perm[k + e];
-                        float gte = (float)xr[ksrc];
-                        if (ACT == 1) {
-                            float sl = gte / (1.f + __expf(-gte));
-                            gte = (float)(f16)sl * (float)xr[a.K + ksrc];
-                        }
-                        v[e] = (f16)gte;
-                    }
-                }
-            }
-            f16x8 p;  // nibble order [0,4,1,5,2,6,3,7]
-            p[0] = v[0]; p[1] = v[4]; p[2] = v[1]; p[3] = v[5];
-            p[4] = v[2]; p[5] = v[6]; p[6] = v[3]; p[7] = v[7];
-            st16(xs + row * rs + c8 * 8, p);
-        }
-    }
-    __syncthreads();
-
-    // ---- dequant + MFMA ------------------------------------------------------------------------
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f32x16 accg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const f16* xrow = xs + (lane & 31) * rs + (lane >> 5) * 32;
-#pragma unroll
-    for (int s = 0; s < MAXSTEPS; ++s) {
-        if (s < nsteps) {
-            const f16* xk = xrow + (st0 + s) * 64;
-            if (GROUP_ACC) {
-                float zf = (float)zz[s];
-                f16 zc1 = (f16)(1024.f + zf), zd1 = (f16)(-64.f - zf);
-                f16x2 zc = {zc1, zc1}, zd = {zd1, zd1};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f16x8 b = dequant8(wq[s][i], zc, zd);
-                    f16x8 av = ld16<f16x8>(xk + i * 8);
-                    accg = mfma32(av, b, accg);
-                }
-                int g = ((ks0 + s) * 64) / a.gs;
-                bool last = (s + 1 == nsteps) || (((ks0 + s + 1) * 64) / a.gs != g);
-                if (last) {
-                    float sf = (float)sc[s];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        acc[r] = fmaf(sf, accg[r], acc[r]);
-                        accg[r] = 0.f;
-                    }
-                }
+        for (int j = 0; j < NJ; ++j) {
+            const int row = srow + RSTEP * j;
+            const f16* xr = xbase + (int64_t)min(row, mrows - 1) * a.ldx;
+            f16x8 v, u;
+            if (!PERM) {
+                v = ld16<f16x8>(xr + kc);
+                if (ACT == 1) u = ld16<f16x8>(xr + a.K + kc);
             } else {
-                // group size not a multiple of 64: scale each k-pack's weights in f16 (exllama-style)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int k = ((ks0 + s) * 8 + (lane >> 5) * 4 + i) * 8;
-                    int g = min(k / a.gs, a.G - 1);
-                    float zf = (float)zbase[g * 32];
-                    f16 sv = sbase[g * 32];
-                    f16 zc1 = (f16)(1024.f + zf), zd1 = (f16)(-64.f - zf);
-                    f16x2 zc = {zc1, zc1}, zd = {zd1, zd1};
-                    f16x8 b = dequant8(wq[s][i], zc, zd);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) b[e] = b[e] * sv;
-                    f16x8 av = ld16<f16x8>(xk + i * 8);
-                    acc = mfma32(av, b, acc);
+                for (int e = 0; e < 8; ++e) {
+                    int ksrc = a.perm[kc + e];
+                    v[e] = xr[ksrc];
+                    if (ACT == 1) u[e] = xr[a.K + ksrc];
                 }
             }
+            xg[j] = v;  // out-of-range rows / columns are zeroed at store time (keeps the loads in flight)
+            if (ACT == 1) xu[j] = u;
+            xok[j] = kok && row < mrows;
         }
+    };
+    auto stage_store = [&](int buf) {
+        f16* dst = xs + buf * (32 * RS) + srow * RS + scol;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            f16x8 t = xok[j] ? xg[j] : zero;
+            if (ACT == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float gte = (float)t[e];
+                    float sl = gte / (1.f + __expf(-gte));
+                    // reference rounds silu(gate) to f16 before the multiply (eager torch ops)
+                    t[e] = (f16)((float)(f16)sl * (float)xu[j][e]);
+                }
+            }
+            st16(dst + j * RSTEP * RS, t);
+        }
+    };
+
+    uint32_t EXr = 0x64006400u, M0r = 0x000F000Fu, M1r = 0x00F000F0u;
+    asm volatile("" : "+v"(EXr));
+    asm volatile("" : "+s"(M0r), "+s"(M1r));
+    // four independent accumulators: the 4 MFMAs of a step do not wait on each other's 16-pass latency
+    f32x16 accs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accs[i] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int xoff = (lane & 31) * RS + (lane >> 5) * 32;
+
+    stage_load(0);
+    stage_store(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        stage_load((a.dbg & 1) ? 0 : min(chunk + 1, nchunks - 1));  // last iteration restages its own chunk
+        // next chunk's scales: issued before this chunk's weight refills so that the loop-carried copy at the
+        // bottom only needs vmcnt(#weight loads) and the weight stream stays in flight across the barrier
+        uint32_t szn[RING];
+        if (GROUP64) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) szn[s4] = sz_at(min(chunk * 4 + s4 + RING, last_step));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f16* xbuf = xs + (chunk & 1) * (32 * RS) + xoff;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int step = chunk * 4 + s4;
+            const u32x4 cur = wq[s4];
+            const int nstep = (a.dbg & 2) ? 0 : min(step + RING, last_step);
+            const f16* xk = xbuf + s4 * 64;
+            f16x8 b[4];
+            if (GROUP64) {
+                const f16x2 szh = __builtin_bit_cast(f16x2, szr[s4]);
+                const f16 zc1 = szh[1];
+                const f16 zd1 = (f16)960.f - zc1;  // -(64 + z + 1), exact
+                const f16x2 zc = {zc1, zc1}, zd = {zd1, zd1}, sc = {szh[0], szh[0]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = dequant8(cur[i], zc, zd, sc, EXr, M0r, M1r);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int k = ((ks0 + step) * 8 + (lane >> 5) * 4 + i) * 8;
+                    int g = min(k / a.gs, a.G - 1);
+                    f16x2 szh = __builtin_bit_cast(f16x2, szp[g * 32]);
+                    f16 zc1 = szh[1], zd1 = (f16)960.f - zc1;
+                    f16x2 zc = {zc1, zc1}, zd = {zd1, zd1}, sc = {szh[0], szh[0]};
+                    b[i] = dequant8(cur[i], zc, zd, sc, EXr, M0r, M1r);
+                }
+            }
+            // slot s4 is consumed: refill it in place for the next chunk (no register copy at the back-edge)
+            __builtin_amdgcn_sched_barrier(0);
+            wq[s4] = __builtin_nontemporal_load(wptr + nstep * 64);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f16x8 av = ld16<f16x8>(xk + i * 8);
+                accs[i] = mfma32(av, b[i], accs[i]);
+            }
+        }
+        stage_store((chunk + 1) & 1);
+        if (GROUP64) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) szr[s4] = szn[s4];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
-    // ---- in-block reduce over the WK k-parts ----------------------------------------------------
-    __syncthreads();  // everyone is done reading the x slab; reuse LDS as [WK][WN][32][32] f32
-    float* red = reinterpret_cast<float*>(smem);
-    {
-        float* dst = red + ((wk * WN + wn) << 10);
-        const int col = lane & 31;
+    // ---- epilogue: lane holds out[m = (r&3)+8(r>>2)+4(lane>>5)][n = nt*32 + (lane&31)] ------------
+    if (nt_raw >= a.NT) return;
+    const f32x16 acc = (accs[0] + accs[1]) + (accs[2] + accs[3]);
+    const int n = nt * 32 + (lane & 31);
+    if (a.S == 1) {
+        const float bv = (a.bias && n < a.N) ? (float)a.bias[n] : 0.f;
+        if (n < a.N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < mrows) a.out[(int64_t)(m0 + m) * a.ldo + n] = (f16)(acc[r] + bv);
+            }
+        }
+    } else {
+        float* sl = a.slabs + ((int64_t)(mslab * a.S + split) * 32) * (a.NT * 32) + n;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            dst[row * 32 + col] = acc[r];
-        }
-    }
-    __syncthreads();
-    // thread -> (tile wn2, row m, 4 consecutive columns)
-    for (int o = tid; o < WN * 256; o += GEMM_THREADS) {
-        int wn2 = o >> 8, m = (o >> 3) & 31, c4 = (o & 7) * 4;
-        int nt2 = ntg * WN + wn2;
-        if (nt2 >= a.NT) continue;
-        f32x4 v = {0, 0, 0, 0};
-#pragma unroll
-        for (int k2 = 0; k2 < WK; ++k2) {
-            f32x4 t = *reinterpret_cast<const f32x4*>(red + ((k2 * WN + wn2) << 10) + m * 32 + c4);
-            v += t;
-        }
-        if (a.S == 1) {
-            if (m < a.M) {
-                int n = nt2 * 32 + c4;
-                f16x4 h;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float f = v[e];
-                    if (a.bias && n + e < a.N) f += (float)a.bias[n + e];
-                    h[e] = (f16)f;
-                }
-                if (n + 3 < a.N) {
-                    *reinterpret_cast<f16x4*>(a.out + (int64_t)m * a.ldo + n) = h;
-                } else {
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < a.N) a.out[(int64_t)m * a.ldo + n + e] = h[e];
-                }
-            }
-        } else {
-            *reinterpret_cast<f32x4*>(a.slabs + (((int64_t)split * a.NT + nt2) << 10) + m * 32 + c4) = v;
-        }
-    }
-    if (a.S == 1) return;
-
-    // ---- cross-block split-K: last arriver sums the S slabs in fixed order (deterministic) -------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // flag lives in the dynamic LDS region (a static __shared__ would misalign its base, guide G17)
-    volatile int* s_last = reinterpret_cast<volatile int*>(smem);
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned t = __hip_atomic_fetch_add(a.counters + ntg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_last = (t == (unsigned)(a.S - 1));
-    }
-    __syncthreads();
-    if (!*s_last) return;
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(a.counters + ntg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    for (int o = tid; o < WN * 256; o += GEMM_THREADS) {
-        int wn2 = o >> 8, m = (o >> 3) & 31, c4 = (o & 7) * 4;
-        int nt2 = ntg * WN + wn2;
-        if (nt2 >= a.NT || m >= a.M) continue;
-        f32x4 v = {0, 0, 0, 0};
-        for (int s2 = 0; s2 < a.S; ++s2) {
-            const float* p = a.slabs + (((int64_t)s2 * a.NT + nt2) << 10) + m * 32 + c4;
-            f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-            v += t;
-        }
-        int n = nt2 * 32 + c4;
-        for (int e = 0; e < 4; ++e) {
-            if (n + e < a.N) {
-                float f = v[e];
-                if (a.bias) f += (float)a.bias[n + e];
-                a.out[(int64_t)m * a.ldo + n + e] = (f16)f;
-            }
+            int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            sl[(int64_t)m * (a.NT * 32)] = acc[r];
         }
     }
 }
 
-__global__ void gptq_dequant_kernel(const uint8_t* __restrict__ prep, int64_t offB, int64_t offC,
-                                    f16* __restrict__ wout, int K, int N, int G, int gs, int NT, int KS) {
+// Sum the S split-K slabs in fixed order (deterministic) and emit f16 (+bias): thread = (row, 4 columns).
+__global__ __launch_bounds__(256) void splitk_reduce_f16_kernel(const float* __restrict__ slabs,
+                                                                const f16* __restrict__ bias, f16* __restrict__ out,
+                                                                int64_t ldo, int M, int N, int NP, int S) {
+    const int np4 = NP >> 2;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int mslab = blockIdx.y;
+    if (idx >= (int64_t)32 * np4) return;
+    const int m = idx / np4, c4 = (idx - (int64_t)m * np4) * 4;
+    if (mslab * 32 + m >= M) return;
+    f32x4 v = {0, 0, 0, 0};
+    const float* base = slabs + ((int64_t)mslab * S * 32 + m) * NP + c4;
+    for (int s2 = 0; s2 < S; ++s2) v += *reinterpret_cast<const f32x4*>(base + (int64_t)s2 * 32 * NP);
+    f16* o = out + (int64_t)(mslab * 32 + m) * ldo + c4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (c4 + e < N) {
+            float f = v[e];
+            if (bias) f += (float)bias[c4 + e];
+            o[e] = (f16)f;
+        }
+    }
+}
+
+__global__ void gptq_dequant_kernel(const uint8_t* __restrict__ prep, int64_t offB, f16* __restrict__ wout,
+                                    int K, int N, int G, int gs, int NT, int KS) {
     // one thread per prepared int32 (8 k of one column)
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)NT * KS * 256) return;
@@ -353,70 +352,48 @@ __global__ void gptq_dequant_kernel(const uint8_t* __restrict__ prep, int64_t of
     if (n >= N || k0 >= K) return;
     uint32_t q = reinterpret_cast<const uint32_t*>(prep)[idx];
     int g = min(k0 / gs, G - 1);
-    float s = (float)reinterpret_cast<const f16*>(prep + offB)[(nt * G + g) * 32 + (l & 31)];
-    float z = (float)prep[offC + (nt * G + g) * 32 + (l & 31)];
+    f16x2 szh = __builtin_bit_cast(f16x2, reinterpret_cast<const uint32_t*>(prep + offB)[(nt * G + g) * 32 + (l & 31)]);
+    float s = (float)szh[0];
+    float z = (float)szh[1] - 1024.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float v = ((float)((q >> (4 * e)) & 15u) - z) * s;
-        wout[(int64_t)(k0 + e) * N + n] = (f16)v;
+    for (int j = 0; j < 8; ++j) {
+        float v = ((float)((q >> (4 * j)) & 15u) - z) * s;
+        wout[(int64_t)(k0 + nib_src(j)) * N + n] = (f16)v;
     }
 }
 
 struct GemmPlan {
-    int WN, KB, S;
-    size_t lds;
+    int KR, S, WN;
 };
 
+// Block = 128 columns x KR rows.  More splits = more blocks in flight but S*M*N*8 bytes of slab traffic
+// and a reduce launch; a wave should stream >= 16 KiB to amortise its prologue/epilogue.
 static GemmPlan plan_gemm(int64_t K, int64_t N) {
-    // Rectangle per block: KB x (32*WN).  Few k-splits (slab traffic = S*M*N*8 B) versus enough blocks
-    // to cover 256 CUs.  LDS = 32*(KB+8)*2 bytes must leave room for >= 1 block/CU.
-    int64_t NT = cdiv64(N, 32);
-    GemmPlan best = {1, 1024, 1, 0};
-    double best_cost = 1e30;
-    const int wns[4] = {1, 2, 4, 8};
-    for (int wi = 0; wi < 4; ++wi) {
-        int WN = wns[wi], WK = 8 / WN;
-        int64_t kbmax = std::min<int64_t>(2048, (int64_t)MAXSTEPS * 64 * WK);
-        for (int64_t S = 1; S <= 64; ++S) {
-            int64_t KB = cdiv64(cdiv64(K, S), 64) * 64;
-            if (KB > kbmax) continue;
-            if ((S - 1) * KB >= K) continue;  // empty last split
-            int64_t blocks = cdiv64(NT, WN) * S;
-            size_t lds = std::max<size_t>(32 * (KB + 8) * 2, 8 * 4096);
-            int per_cu = std::min<int>(4, (int)(160 * 1024 / (lds + 64)));
-            if (per_cu < 1) continue;
-            double rounds = (double)blocks / (256.0 * per_cu);
-            double fill = rounds < 1.0 ? 1.0 : (std::ceil(rounds) / rounds);
-            // bytes: weights + x restaging through L2 (cheaper, x0.25) + slab round trip (x2, when S>1)
-            double wbytes = (double)K * N / 2;
-            double xbytes = (double)blocks * 32 * KB * 2 * 0.25;
-            double sbytes = S > 1 ? (double)S * 32 * N * 4 * 2.0 : 0.0;
-            double under = blocks < 256 ? 256.0 / blocks : 1.0;  // idle CUs
-            double cost = (wbytes + xbytes + sbytes) * fill * under;
-            if (cost < best_cost) {
-                best_cost = cost;
-                best = {WN, (int)KB, (int)S, lds};
-            }
-        }
+    if (const char* ov = getenv("TGIS_GPTQ_PLAN")) {  // tuning hook: "KR,S,WN"
+        int kr = 0, sp = 0, wn = 0;
+        if (sscanf(ov, "%d,%d,%d", &kr, &sp, &wn) == 3 && kr > 0 && kr % KC == 0 && (int64_t)sp * kr >= K &&
+            (int64_t)(sp - 1) * kr < K && (wn == 4 || wn == 8))
+            return {kr, sp, wn};
+    }
+    const int WN = 4;
+    const int64_t tiles = cdiv64(N, 32);
+    const int64_t colblocks = cdiv64(tiles, WN);
+    const int64_t kchunks = cdiv64(K, KC);
+    // Measured on MI355X (tools/sweep_gptq.py, profiles/): the kernel is bound by per-step instruction
+    // issue, not by HBM, so extra splits only add slab traffic and a reduce launch.  Take the smallest S
+    // that puts a wave on most SIMDs (>= 680 waves) while each wave still streams >= 2 chunks.
+    GemmPlan best = {(int)(kchunks * KC), 1, WN};
+    for (int64_t S = 1; S <= kchunks; ++S) {
+        int64_t KRc = cdiv64(kchunks, S);
+        if ((S - 1) * KRc >= kchunks) continue;  // empty last split
+        best = {(int)(KRc * KC), (int)S, WN};
+        if (tiles * S >= 680 || KRc <= 2) break;
     }
     return best;
 }
 
-template <int WN, int ACT>
-static void launch_gemm(const GemmArgs& a, bool group_acc, dim3 grid, size_t lds, hipStream_t st) {
-    if (group_acc)
-        hipLaunchKernelGGL((gptq_gemm_kernel<WN, ACT, true>), grid, dim3(GEMM_THREADS), lds, st, a);
-    else
-        hipLaunchKernelGGL((gptq_gemm_kernel<WN, ACT, false>), grid, dim3(GEMM_THREADS), lds, st, a);
-}
-
-template <int WN, int ACT>
-static hipError_t set_lds_attr(size_t lds) {
-    hipError_t e = hipFuncSetAttribute((const void*)gptq_gemm_kernel<WN, ACT, true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)gptq_gemm_kernel<WN, ACT, false>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+static int64_t slab_bytes(int64_t M, int64_t N, int S) {
+    return S > 1 ? cdiv64(M, 32) * S * 32 * cdiv64(N, 32) * 32 * 4 : 0;
 }
 
 }  // namespace
@@ -464,16 +441,14 @@ extern "C" int tgis_gptq_prepare(const int32_t* qweight, const int32_t* qzeros, 
     TGIS_CHECK_LAUNCH();
     int64_t totalB = p.NT * groups * 32;
     hipLaunchKernelGGL(gptq_prepare_sz_kernel, dim3((unsigned)cdiv64(totalB, 256)), dim3(256), 0, st, qzeros,
-                       (const f16*)scales, (f16*)(base + p.offB), base + p.offC, N, p.NT, groups);
+                       (const f16*)scales, (uint32_t*)(base + p.offB), N, p.NT, groups);
     TGIS_CHECK_LAUNCH();
     return TGIS_OK;
 }
 
 extern "C" int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N) {
-    (void)M;
     GemmPlan pl = plan_gemm(K, N);
-    int64_t NT = cdiv64(N, 32);
-    return 4096 + (pl.S > 1 ? (int64_t)pl.S * NT * 4096 : 0);
+    return 4096 + slab_bytes(M, N, pl.S);
 }
 
 extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepared, const void* bias,
@@ -485,71 +460,72 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
     TGIS_CHECK_ARG(groups > 0 && K % groups == 0, "tgis_gptq_gemm_f16: K %% groups != 0");
     TGIS_CHECK_ARG(act == 0 || act == 1, "tgis_gptq_gemm_f16: act must be 0 or 1");
     TGIS_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, "tgis_gptq_gemm_f16: x must be 16-byte aligned rows");
-    TGIS_CHECK_ARG(ldo % 4 == 0 && ((uintptr_t)out % 8) == 0, "tgis_gptq_gemm_f16: out rows must be 8-byte aligned");
     if (M == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
     PrepLayout p = prep_layout(K, N, groups);
     GemmPlan pl = plan_gemm(K, N);
-    int64_t need = 4096 + (pl.S > 1 ? (int64_t)pl.S * p.NT * 4096 : 0);
+    const int64_t mslabs = cdiv64(M, 32);
+    TGIS_CHECK_ARG(mslabs <= 65535, "tgis_gptq_gemm_f16: M too large for one launch");
+    int64_t need = 4096 + slab_bytes(M, N, pl.S);
     TGIS_CHECK_ARG(workspace && workspace_bytes >= need, "tgis_gptq_gemm_f16: workspace too small (%ld < %ld)",
                    (long)workspace_bytes, (long)need);
-    TGIS_CHECK_ARG(cdiv64(p.NT, pl.WN) <= 1024, "tgis_gptq_gemm_f16: N too large for the counter region");
     const int64_t gs = K / groups;
-    const bool group_acc = (gs % 64 == 0) || groups == 1;
-
-    static bool attr_done[4][2] = {};
-    int wi = pl.WN == 1 ? 0 : pl.WN == 2 ? 1 : pl.WN == 4 ? 2 : 3;
-    if (!attr_done[wi][act]) {
-        hipError_t e = hipSuccess;
-        size_t mx = 150 * 1024;
-        switch (pl.WN * 2 + act) {
-            case 2: e = set_lds_attr<1, 0>(mx); break;
-            case 3: e = set_lds_attr<1, 1>(mx); break;
-            case 4: e = set_lds_attr<2, 0>(mx); break;
-            case 5: e = set_lds_attr<2, 1>(mx); break;
-            case 8: e = set_lds_attr<4, 0>(mx); break;
-            case 9: e = set_lds_attr<4, 1>(mx); break;
-            case 16: e = set_lds_attr<8, 0>(mx); break;
-            case 17: e = set_lds_attr<8, 1>(mx); break;
-        }
-        TGIS_CHECK_HIP(e);
-        attr_done[wi][act] = true;
-    }
+    const bool group64 = (gs % 64 == 0) || groups == 1;
 
     TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
     GemmArgs a;
+    a.x = (const f16*)x;
+    a.ldx = ldx;
     a.prep = (const uint8_t*)prepared;
     a.offB = p.offB;
-    a.offC = p.offC;
     a.bias = (const f16*)bias;
     a.perm = perm;
-    a.ldx = ldx;
+    a.out = (f16*)out;
     a.ldo = ldo;
+    a.M = (int)M;
     a.K = (int)K;
     a.N = (int)N;
     a.G = (int)groups;
     a.gs = (int)gs;
-    a.KB = pl.KB;
+    a.KR = pl.KR;
     a.S = pl.S;
     a.NT = (int)p.NT;
     a.KS = (int)p.KS;
-    a.counters = (unsigned*)workspace;
     a.slabs = (float*)((uint8_t*)workspace + 4096);
-    dim3 grid((unsigned)cdiv64(p.NT, pl.WN), (unsigned)pl.S);
-    for (int64_t m0 = 0; m0 < M; m0 += 32) {
-        a.x = (const f16*)x + m0 * ldx;
-        a.out = (f16*)out + m0 * ldo;
-        a.M = (int)std::min<int64_t>(32, M - m0);
-        switch (pl.WN * 2 + act) {
-            case 2: launch_gemm<1, 0>(a, group_acc, grid, pl.lds, st); break;
-            case 3: launch_gemm<1, 1>(a, group_acc, grid, pl.lds, st); break;
-            case 4: launch_gemm<2, 0>(a, group_acc, grid, pl.lds, st); break;
-            case 5: launch_gemm<2, 1>(a, group_acc, grid, pl.lds, st); break;
-            case 8: launch_gemm<4, 0>(a, group_acc, grid, pl.lds, st); break;
-            case 9: launch_gemm<4, 1>(a, group_acc, grid, pl.lds, st); break;
-            case 16: launch_gemm<8, 0>(a, group_acc, grid, pl.lds, st); break;
-            case 17: launch_gemm<8, 1>(a, group_acc, grid, pl.lds, st); break;
-        }
+    {
+        const char* d = getenv("TGIS_GPTQ_DBG");
+        a.dbg = d ? atoi(d) : 0;
+    }
+    dim3 grid((unsigned)cdiv64(p.NT, pl.WN), (unsigned)pl.S, (unsigned)mslabs);
+    const size_t lds = 2 * 32 * RS * sizeof(f16);
+#define TGIS_LAUNCH_GEMM(W, A, G, P) \
+    hipLaunchKernelGGL((gptq_gemm_kernel<W, A, G, P>), grid, dim3(64 * W), lds, st, a)
+#define TGIS_LAUNCH_GEMM_W(A, G, P)             \
+    do {                                        \
+        if (pl.WN == 8)                         \
+            TGIS_LAUNCH_GEMM(8, A, G, P);       \
+        else                                    \
+            TGIS_LAUNCH_GEMM(4, A, G, P);       \
+    } while (0)
+    const int variant = (act ? 4 : 0) | (group64 ? 2 : 0) | (perm ? 1 : 0);
+    switch (variant) {
+        case 0: TGIS_LAUNCH_GEMM_W(0, false, false); break;
+        case 1: TGIS_LAUNCH_GEMM_W(0, false, true); break;
+        case 2: TGIS_LAUNCH_GEMM_W(0, true, false); break;
+        case 3: TGIS_LAUNCH_GEMM_W(0, true, true); break;
+        case 4: TGIS_LAUNCH_GEMM_W(1, false, false); break;
+        case 5: TGIS_LAUNCH_GEMM_W(1, false, true); break;
+        case 6: TGIS_LAUNCH_GEMM_W(1, true, false); break;
+        case 7: TGIS_LAUNCH_GEMM_W(1, true, true); break;
+    }
+#undef TGIS_LAUNCH_GEMM_W
+#undef TGIS_LAUNCH_GEMM
+    TGIS_CHECK_LAUNCH();
+    if (pl.S > 1 && !getenv("TGIS_GPTQ_NOREDUCE")) {
+        const int NP = (int)p.NT * 32;
+        dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 4), 256), (unsigned)mslabs);
+        hipLaunchKernelGGL(splitk_reduce_f16_kernel, rgrid, dim3(256), 0, st, a.slabs, a.bias, a.out, a.ldo, a.M, a.N,
+                           NP, a.S);
         TGIS_CHECK_LAUNCH();
     }
     return TGIS_OK;
@@ -562,7 +538,7 @@ extern "C" int tgis_gptq_dequant_f16(const void* prepared, void* w_out, int64_t 
     PrepLayout p = prep_layout(K, N, groups);
     int64_t total = p.NT * p.KS * 256;
     hipLaunchKernelGGL(gptq_dequant_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint8_t*)prepared, p.offB, p.offC, (f16*)w_out, (int)K, (int)N, (int)groups,
+                       (const uint8_t*)prepared, p.offB, (f16*)w_out, (int)K, (int)N, (int)groups,
                        (int)(K / groups), (int)p.NT, (int)p.KS);
     TGIS_CHECK_LAUNCH();
     return TGIS_OK;

@@ -1,0 +1,242 @@
+"""Llama (MHA / GQA) forward for prefill and batched decode on the gfx950 kernels of libtgis_hip.so.
+
+Mirrors custom_modeling/flash_llama_modeling.py of the reference — `LlamaConfig` (:37-99), `LlamaRMSNorm`
+(:102-152), `FlashLlamaAttention` (:183-297), `LlamaMLP` (:300-335), `FlashLlamaLayer` (:338-395),
+`FlashLlamaModel` (:398-497), `FlashLlamaForCausalLM` (:500-540) — with these deliberate differences:
+  * the KV cache is the paged pool of utils/kv_cache.py instead of a per-batch contiguous tensor, so
+    `forward` takes a `KVArgs` (block tables, context lengths, slots) where the reference takes
+    `past_key_values` / `pre_allocate_past_size`;
+  * RoPE, the KV write and the q/k/v split are one kernel; SiLU*mul is fused into down_proj's operand
+    staging; every residual-add is fused into the following RMSNorm (as in the reference);
+  * logits are produced in fp32.
+Tensor-parallel sharding follows the reference exactly (heads split across ranks, qkv / gate_up
+column-parallel, o_proj / down_proj row-parallel + all-reduce, vocab-parallel embedding and head)."""
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from tgis_amd import native
+from tgis_amd.utils.layers import (
+    PositionRotaryEmbedding,
+    TensorParallelColumnLinear,
+    TensorParallelEmbedding,
+    TensorParallelHead,
+    TensorParallelRowLinear,
+)
+
+
+class LlamaConfig:
+    """The subset of the HF Llama config the forward needs (reference :37-99; eps default 1e-6 there)."""
+
+    def __init__(self, vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
+                 num_attention_heads=32, num_key_value_heads=None, hidden_act="silu", max_position_embeddings=2048,
+                 rms_norm_eps=1e-6, rope_scaling=None, rope_theta=10000.0, attention_bias=False, mlp_bias=False,
+                 pad_token_id=None, bos_token_id=1, eos_token_id=2, tie_word_embeddings=False, quantize=None,
+                 **kwargs):
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.intermediate_size = intermediate_size
+        self.num_hidden_layers = num_hidden_layers
+        self.num_attention_heads = num_attention_heads
+        self.num_key_value_heads = num_key_value_heads if num_key_value_heads is not None else num_attention_heads
+        self.hidden_act = hidden_act
+        self.max_position_embeddings = max_position_embeddings
+        self.rms_norm_eps = rms_norm_eps
+        self.rope_scaling = rope_scaling
+        self.rope_theta = rope_theta
+        self.attention_bias = attention_bias
+        self.mlp_bias = mlp_bias
+        self.pad_token_id = pad_token_id
+        self.bos_token_id = bos_token_id
+        self.eos_token_id = eos_token_id
+        self.tie_word_embeddings = tie_word_embeddings
+        self.quantize = quantize
+        self.model_type = "llama"
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def to_dict(self):
+        return dict(vars(self))
+
+
+@dataclass
+class KVArgs:
+    """Where this forward's keys/values live in the paged cache."""
+    cache: "object"                    # utils.kv_cache.PagedKVCache
+    block_tables: torch.Tensor         # [B, max_pages] int32 (device)
+    ctx_lens: Optional[torch.Tensor]   # [B] int32, tokens per sequence incl. this forward's (prefill); decode: filled in
+    slots: Optional[torch.Tensor]      # [T] int32 physical slot per token (prefill); decode: filled in
+    max_q_len: int                     # longest q run in this forward (1 for decode)
+    max_ctx: int                       # upper bound of ctx_lens (launch shaping only)
+    num_splits: int = 1                # attention key splits (decode)
+
+
+class LlamaRMSNorm:
+    def __init__(self, prefix, weights, eps=1e-6):
+        self.weight = weights.get_tensor(f"{prefix}.weight").contiguous()
+        self.variance_epsilon = eps
+
+    def forward(self, hidden_states, residual=None):
+        # returns (normed, res) like the reference; res is hidden_states itself when residual is None
+        return native.rmsnorm_residual(hidden_states, residual, self.weight, self.variance_epsilon)
+
+    __call__ = forward
+
+
+class FlashLlamaAttention:
+    def __init__(self, prefix: str, config, weights):
+        self.num_heads = config.num_attention_heads
+        self.hidden_size = config.hidden_size
+        self.head_size = self.hidden_size // self.num_heads
+        scaling = 1.0
+        if config.rope_scaling and "type" in config.rope_scaling:
+            if config.rope_scaling["type"] == "linear":
+                scaling = config.rope_scaling.get("factor", 1.0)
+            else:
+                raise ValueError(f"rope_scaling of type {config.rope_scaling['type']} is not supported")
+        self.rotary_emb = PositionRotaryEmbedding.static(dim=self.head_size, base=config.rope_theta,
+                                                         device=weights.device, scaling_factor=scaling)
+        self.softmax_scale = self.head_size ** -0.5
+        tp = weights.process_group.size()
+        if self.num_heads % tp != 0:
+            raise ValueError(f"`num_heads` must be divisible by `num_shards` (got `num_heads`: {self.num_heads} "
+                             f"and `num_shards`: {tp}")
+        assert config.num_key_value_heads % tp == 0, "num_key_value_heads must be divisible by the shard count"
+        self.num_heads = self.num_heads // tp
+        self.num_key_value_heads = config.num_key_value_heads // tp
+        self.query_key_value = TensorParallelColumnLinear.load_multi(
+            config, prefixes=[f"{prefix}.q_proj", f"{prefix}.k_proj", f"{prefix}.v_proj"], dim=0, weights=weights,
+            bias=config.attention_bias)
+        self.o_proj = TensorParallelRowLinear.load(config, prefix=f"{prefix}.o_proj", weights=weights,
+                                                   bias=config.attention_bias)
+
+    def forward(self, hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id: int, kv: KVArgs):
+        H, Hkv, D = self.num_heads, self.num_key_value_heads, self.head_size
+        qkv = self.query_key_value(hidden_states)  # [T, (H + 2 Hkv) D]
+        k_pool, v_pool = kv.cache.k_pool(layer_id), kv.cache.v_pool(layer_id)
+        # rotate q,k in place and scatter k,v to their page slots (reference :252-268,282)
+        native.rope_kv_write(qkv, cos, sin, position_ids, kv.slots, k_pool, v_pool, H, Hkv, D, D)
+        T = qkv.shape[0]
+        attn_output = torch.empty((T, H * D), dtype=qkv.dtype, device=qkv.device)
+        B = kv.block_tables.shape[0]
+        ws = None
+        if kv.num_splits > 1:
+            from tgis_amd.utils.layers import workspace
+            ws = workspace(qkv.device)
+            ws.ensure(native.attn_workspace_bytes(T, H, D, kv.num_splits))
+        native.attn_paged(qkv, qkv.stride(0), k_pool, v_pool, kv.block_tables, kv.ctx_lens, cu_seqlens_q,
+                          attn_output, B, H, Hkv, D, kv.max_q_len, kv.max_ctx, self.softmax_scale, kv.num_splits, ws)
+        return self.o_proj(attn_output)
+
+    __call__ = forward
+
+
+class LlamaMLP:
+    def __init__(self, prefix, config, weights):
+        if config.hidden_act != "silu":
+            raise NotImplementedError(f"hidden_act {config.hidden_act}: only silu is wired into the fused kernel")
+        self.gate_up_proj = TensorParallelColumnLinear.load_multi(
+            config, prefixes=[f"{prefix}.gate_proj", f"{prefix}.up_proj"], weights=weights, dim=0,
+            bias=config.mlp_bias)
+        self.down_proj = TensorParallelRowLinear.load(config, prefix=f"{prefix}.down_proj", weights=weights,
+                                                      bias=config.mlp_bias)
+        self.intermediate_size = config.intermediate_size // weights.process_group.size()
+
+    def forward(self, hidden_states):
+        gate_up_states = self.gate_up_proj(hidden_states)  # [T, 2, I]
+        # act(gate) * up is applied while down_proj stages its operand (reference :332-335)
+        return self.down_proj(gate_up_states, act=1)
+
+    __call__ = forward
+
+
+class FlashLlamaLayer:
+    def __init__(self, layer_id, config, weights):
+        prefix = f"model.layers.{layer_id}"
+        self.layer_id = layer_id
+        self.self_attn = FlashLlamaAttention(prefix=f"{prefix}.self_attn", config=config, weights=weights)
+        self.mlp = LlamaMLP(prefix=f"{prefix}.mlp", config=config, weights=weights)
+        self.input_layernorm = LlamaRMSNorm(prefix=f"{prefix}.input_layernorm", weights=weights,
+                                            eps=config.rms_norm_eps)
+        self.post_attention_layernorm = LlamaRMSNorm(prefix=f"{prefix}.post_attention_layernorm", weights=weights,
+                                                     eps=config.rms_norm_eps)
+
+    def forward(self, hidden_states, residual, cos, sin, position_ids, cu_seqlens_q, kv: KVArgs):
+        normed_hidden_states, res = self.input_layernorm(hidden_states, residual)
+        attn_output = self.self_attn(normed_hidden_states, cos, sin, position_ids, cu_seqlens_q, self.layer_id, kv)
+        normed_attn_res_output, attn_res = self.post_attention_layernorm(attn_output, res)
+        mlp_output = self.mlp(normed_attn_res_output)
+        return mlp_output, attn_res
+
+    __call__ = forward
+
+
+class FlashLlamaModel:
+    def __init__(self, config, weights):
+        self.config = config
+        process_group = weights.process_group
+        self.tp_rank = process_group.rank()
+        self.tp_world_size = process_group.size()
+        self.embed_tokens = TensorParallelEmbedding(prefix="model.embed_tokens", weights=weights)
+        self.layers = [FlashLlamaLayer(i, config, weights) for i in range(config.num_hidden_layers)]
+        self.norm = LlamaRMSNorm(prefix="model.norm", weights=weights, eps=config.rms_norm_eps)
+        self.head_size = self.layers[0].self_attn.head_size
+        self.num_heads = self.layers[0].self_attn.num_heads
+        self.num_key_value_heads = config.num_key_value_heads // process_group.size()
+        self.max_positions = 0
+
+    def rope_tables(self, dtype, device, max_s: int):
+        # grown geometrically so that captured decode graphs keep valid table pointers
+        if max_s > self.max_positions:
+            self.max_positions = max(max_s, 2 * self.max_positions, 2048)
+        return self.layers[0].self_attn.rotary_emb.tables(dtype, device, self.max_positions)
+
+    def forward(self, input_ids, position_ids, cu_seqlens_q, max_s, inputs_embeds, kv: KVArgs):
+        if input_ids is not None and inputs_embeds is not None:
+            raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+        hidden_states = inputs_embeds if inputs_embeds is not None else self.embed_tokens(input_ids)
+        cos, sin = self.rope_tables(hidden_states.dtype, hidden_states.device, max_s)
+        residual = None
+        for layer in self.layers:
+            hidden_states, residual = layer(hidden_states, residual, cos, sin, position_ids, cu_seqlens_q, kv)
+        hidden_states, _ = self.norm(hidden_states, residual)
+        return hidden_states
+
+    __call__ = forward
+
+
+class FlashLlamaForCausalLM:
+    def __init__(self, config, weights):
+        self.config = config
+        self.model = FlashLlamaModel(config, weights)
+        self.lm_head = TensorParallelHead.load(config, prefix="lm_head", weights=weights)
+        self.gptq_linears: List = []
+        for layer in self.model.layers:
+            for lin in (layer.self_attn.query_key_value.linear, layer.self_attn.o_proj.linear,
+                        layer.mlp.gate_up_proj.linear, layer.mlp.down_proj.linear):
+                if hasattr(lin, "post_init"):
+                    self.gptq_linears.append(lin)
+
+    def post_init(self):
+        """Repack every GPTQ linear for the kernels (the reference does this in serve(), server.py:334-358)."""
+        for lin in self.gptq_linears:
+            if lin.q_handle is None:
+                lin.post_init()
+
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+    @property
+    def num_layers(self):
+        return len(self.model.layers)
+
+    def forward(self, input_ids, position_ids, cu_seqlens_q, max_s, inputs_embeds=None, kv: KVArgs = None,
+                lm_head_indices: Optional[torch.Tensor] = None):
+        """position_ids int32 [T]; returns fp32 logits [T or len(lm_head_indices), vocab]."""
+        hidden_states = self.model(input_ids, position_ids, cu_seqlens_q, max_s, inputs_embeds, kv)
+        if lm_head_indices is not None:
+            hidden_states = hidden_states.index_select(0, lm_head_indices)
+        return self.lm_head(hidden_states)
+
+    __call__ = forward

@@ -1,0 +1,486 @@
+"""FlashCausalLMBatch + FlashCausalLM: the batched prefill/decode hot path on the MI355X kernels.
+
+Mirrors models/flash_causal_lm.py of the reference: batch fields and `from_pb` (:28-194), `concatenate`
+(:196-285), `prune` (:290-353), `generate_token` (:405-460), `_process_prefill/_decode/_new_tokens`
+(:462-588).  Same names, same argument meaning, same returned tuple, same logical bookkeeping
+(`cu_seqlens`, `cu_seqlens_q`, `max_seqlen`, `position_ids`, `all_input_ids_tensor`, `input_lengths`).
+
+What is different by design:
+  * `past_key_values` is always None: KV lives in the model's PagedKVCache and a batch owns a list of page
+    ids per request.  The reference re-concatenates the whole KV tensor on every decode step for B > 1
+    (:439-447) and on every concatenate/prune; here those are page-table edits.
+  * the decode step (embedding -> layers -> head -> greedy) is replayed from a captured HIP graph keyed by
+    (batch size, block-table width); the only host<->device traffic per step is three small input copies
+    and, for plain greedy batches, one copy of `[B]` token ids (+ logprobs) instead of B `.item()` syncs
+    (reference :546-586 / utils/tokens.py:394).
+"""
+import logging
+import os
+import time
+from dataclasses import dataclass
+from operator import itemgetter
+from typing import Any, List, Optional, Tuple, Type, Union
+
+import numpy as np
+import torch
+
+from tgis_amd import native
+from tgis_amd.models.custom_modeling.flash_llama_modeling import KVArgs
+from tgis_amd.models.model import Model
+from tgis_amd.models.types import Batch, GenerateError
+from tgis_amd.pb import generate_pb2
+from tgis_amd.utils.kv_cache import PAGE, PagedKVCache
+from tgis_amd.utils.token_types import InputTokens, TokenInfo
+from tgis_amd.utils.tokens import HeterogeneousNextTokenChooser, get_input_tokens_info, get_token_info
+
+USE_GRAPHS = os.getenv("TGIS_DISABLE_GRAPHS", "false").lower() not in ("1", "true")
+
+
+@dataclass
+class FlashCausalLMBatch(Batch):
+    batch_id: int
+    requests: List[generate_pb2.Request]
+
+    # tensors hold the sequences of the batch concatenated: [sum(seq_lengths)] (prefill) / [B] (decode)
+    input_ids: Optional[torch.Tensor]
+    position_ids: torch.Tensor
+    inputs_embeds: Optional[torch.Tensor]
+    # cumulative (logical) sequence lengths, and cumulative query lengths (decode only)
+    cu_seqlens: torch.Tensor
+    cu_seqlens_q: Optional[torch.Tensor]
+    # kept for the servicer's clean_attribute("past_key_values") call; always None (paged cache)
+    past_key_values: Optional[torch.Tensor]
+    # maximum of the input lengths across the batch (including prefix)
+    max_seqlen: int
+
+    all_input_ids_tensor: torch.Tensor
+    input_lengths: List[int]
+    # (truncated) input length + prefix length + max output tokens: sizes all_input_ids_tensor and the pages
+    total_lengths: List[int]
+    pad_token_id: int
+
+    next_token_chooser: HeterogeneousNextTokenChooser
+
+    # paged-KV ownership: page ids per request, filled by the prefill generate_token
+    kv_cache: Optional[PagedKVCache] = None
+    pages: Optional[List[List[int]]] = None
+    block_tables: Optional[torch.Tensor] = None
+
+    def get_id(self) -> int:
+        return self.batch_id
+
+    def __len__(self):
+        return len(self.requests)
+
+    # ---- page ownership --------------------------------------------------------------------------
+    def allocate_pages(self, kv_cache: PagedKVCache):
+        assert self.pages is None
+        need = [PagedKVCache.pages_for(t) for t in self.total_lengths]
+        flat = kv_cache.alloc(sum(need))  # raises OutOfPages before anything is taken
+        self.kv_cache = kv_cache
+        self.pages, o = [], 0
+        for n in need:
+            self.pages.append(flat[o:o + n])
+            o += n
+        self._rebuild_block_tables()
+
+    def _rebuild_block_tables(self):
+        width = max(len(p) for p in self.pages)
+        width = (width + 7) // 8 * 8  # few distinct widths -> few captured graphs
+        bt = np.zeros((len(self.pages), width), dtype=np.int32)
+        for i, p in enumerate(self.pages):
+            bt[i, :len(p)] = p
+        self.block_tables = torch.from_numpy(bt).to(self.cu_seqlens.device, non_blocking=True)
+
+    def release(self):
+        if self.pages is not None and self.kv_cache is not None:
+            for p in self.pages:
+                self.kv_cache.free(p)
+        self.pages = None
+        self.block_tables = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    # ---- construction ---------------------------------------------------------------------------------
+    @classmethod
+    def from_pb(cls, pb: generate_pb2.Batch, tokenizer, dtype: torch.dtype, device: torch.device,
+                embeddings_lookup: Optional, prefix_cache: Optional, use_position_ids: bool = True,
+                ) -> Tuple[Optional["FlashCausalLMBatch"], List[GenerateError]]:
+        errors: List[GenerateError] = []
+        requests, batch_inputs, prefix_embeds_by_index = [], [], {}
+        input_lengths, total_lengths = [], []
+        cu_seqlens = [0]
+        for r in pb.requests:
+            input_length = r.input_length
+            if r.prefix_id:
+                try:
+                    prefix_embeds = prefix_cache.get(r.prefix_id)
+                except Exception:
+                    message = f"Prefix lookup error for request #{r.id}, prefix id {r.prefix_id}"
+                    logging.error(message)
+                    errors.append(GenerateError(request_id=r.id, message=message))
+                    continue  # the request is left out of the batch
+                prefix_embeds_by_index[len(requests)] = prefix_embeds
+                input_length += prefix_embeds.shape[0]  # input_lengths include the prefix
+            requests.append(r)
+            batch_inputs.append(r.inputs)
+            input_lengths.append(input_length)
+            total_lengths.append(input_length + r.max_output_length)
+            cu_seqlens.append(cu_seqlens[-1] + input_length)
+        if not requests:
+            return None, errors
+        max_seqlen = max(input_lengths)
+
+        # no padding: sequences are concatenated across the batch
+        tokenized = tokenizer(batch_inputs, truncation=True, max_length=max_seqlen,
+                              return_token_type_ids=False)["input_ids"]
+        all_input_ids_tensor = torch.full((len(requests), max(total_lengths)), tokenizer.pad_token_id,
+                                          dtype=torch.int64, device=device)
+        input_ids, position_ids, chooser_params, return_logprobs = [], [], [], []
+        for i, (r, toks, input_length) in enumerate(zip(requests, tokenized, input_lengths)):
+            if r.truncate:
+                toks = toks[-r.input_length:]
+                if getattr(tokenizer, "add_bos_token", False):
+                    toks[0] = tokenizer.bos_token_id  # keep a BOS at the front after left-truncation
+            toks = all_input_ids_tensor.new_tensor(toks)
+            # a prefix occupies the first (input_length - r.input_length) positions as pad ids
+            all_input_ids_tensor[i, input_length - r.input_length:input_length] = toks
+            input_ids.append(toks if input_length == r.input_length else all_input_ids_tensor[i, :input_length])
+            chooser_params.append(r.parameters)
+            return_logprobs.append(r.details.logprobs)
+            position_ids.append(torch.arange(0, input_length))
+        input_ids = torch.cat(input_ids)
+
+        if prefix_embeds_by_index:
+            inputs_embeds = embeddings_lookup(input_ids)
+            input_ids = None
+            for i, p in prefix_embeds_by_index.items():
+                inputs_embeds[cu_seqlens[i]:cu_seqlens[i] + p.shape[0], :] = p
+        else:
+            inputs_embeds = None
+
+        next_token_chooser = HeterogeneousNextTokenChooser.from_pb(
+            pb=chooser_params,
+            model_eos_token_id=getattr(tokenizer, "model_eos_token_id", tokenizer.eos_token_id),
+            model_pad_token_id=tokenizer.pad_token_id,
+            return_logprobs=return_logprobs, dtype=torch.float32, device=device)
+
+        return cls(
+            batch_id=pb.id, requests=requests, input_ids=input_ids, inputs_embeds=inputs_embeds,
+            position_ids=torch.cat(position_ids).to(device, non_blocking=True),
+            cu_seqlens=torch.tensor(cu_seqlens, dtype=torch.int32, device=device), cu_seqlens_q=None,
+            max_seqlen=max_seqlen, past_key_values=None, input_lengths=input_lengths,
+            total_lengths=total_lengths, all_input_ids_tensor=all_input_ids_tensor,
+            next_token_chooser=next_token_chooser, pad_token_id=tokenizer.pad_token_id,
+        ), errors
+
+    @classmethod
+    def concatenate(cls, batches: List["FlashCausalLMBatch"]) -> "FlashCausalLMBatch":
+        first = batches[0]
+        device = first.cu_seqlens_q.device
+        requests, input_lengths, total_lengths, pages = [], [], [], []
+        chooser_params, ntc_current_tokens, ntc_samplings, ntc_return_logprobs = [], [], [], []
+        input_ids, position_ids = [], []
+        cu_seqlens = [torch.tensor([0], dtype=torch.int32, device=device)]
+        new_batch_size = sum(len(b) for b in batches)
+        max_total_length = max(t for b in batches for t in b.total_lengths)
+        all_input_ids_tensor = first.all_input_ids_tensor.new_full((new_batch_size, max_total_length),
+                                                                   first.pad_token_id)
+        cumulative_length = torch.tensor(0, device=device)
+        start, max_seqlen = 0, 0
+        for batch in batches:
+            requests.extend(batch.requests)
+            input_lengths.extend(batch.input_lengths)
+            total_lengths.extend(batch.total_lengths)
+            chooser_params.extend(r.parameters for r in batch.requests)
+            ntc_current_tokens.extend(batch.next_token_chooser.current_tokens)
+            ntc_samplings.extend(batch.next_token_chooser.samplings)
+            ntc_return_logprobs.extend(batch.next_token_chooser.return_logprobs)
+            cu_seqlens.append(batch.cu_seqlens[1:] + cumulative_length)
+            input_ids.append(batch.input_ids)
+            position_ids.append(batch.position_ids)
+            # page ownership moves to the merged batch; no KV bytes move (reference: torch.cat of the pasts)
+            pages.extend(batch.pages)
+            batch.pages = None
+            batch.block_tables = None
+            end = start + len(batch)
+            all_input_ids_tensor[start:end, :batch.all_input_ids_tensor.shape[1]] = batch.all_input_ids_tensor
+            start = end
+            max_seqlen = max(max_seqlen, batch.max_seqlen)
+            cumulative_length += batch.cu_seqlens[-1]
+
+        ntc0 = first.next_token_chooser
+        next_token_chooser = HeterogeneousNextTokenChooser.from_pb(
+            pb=chooser_params, model_eos_token_id=ntc0.eos_token_id, model_pad_token_id=ntc0.pad_token_id,
+            return_logprobs=ntc_return_logprobs, dtype=ntc0.dtype, device=ntc0.device,
+            samplings=ntc_samplings, current_tokens=ntc_current_tokens)
+
+        merged = FlashCausalLMBatch(
+            batch_id=first.batch_id, requests=requests, input_ids=torch.cat(input_ids), inputs_embeds=None,
+            position_ids=torch.cat(position_ids), cu_seqlens=torch.cat(cu_seqlens),
+            cu_seqlens_q=torch.arange(len(requests) + 1, device=device, dtype=torch.int32),
+            max_seqlen=max_seqlen, past_key_values=None, input_lengths=input_lengths,
+            total_lengths=total_lengths, all_input_ids_tensor=all_input_ids_tensor,
+            next_token_chooser=next_token_chooser, pad_token_id=first.pad_token_id,
+            kv_cache=first.kv_cache, pages=pages)
+        merged._rebuild_block_tables()
+        return merged
+
+    @classmethod
+    def prune(cls, batch: "FlashCausalLMBatch", completed_ids: List[int]) -> Optional["FlashCausalLMBatch"]:
+        """Drop completed requests; their pages go back to the pool."""
+        if not completed_ids:
+            return batch
+        keep_indices = Model.get_indices_to_keep(batch.requests, completed_ids)
+        new_size = len(keep_indices)
+        if new_size == 0:
+            batch.release()
+            return None
+        keep = set(keep_indices)
+        for i, p in enumerate(batch.pages):
+            if i not in keep:
+                batch.kv_cache.free(p)
+        pick = (lambda l: [l[i] for i in keep_indices])
+        batch.pages = pick(batch.pages)
+        batch.input_lengths = pick(batch.input_lengths)
+        batch.total_lengths = pick(batch.total_lengths)
+        batch.requests = pick(batch.requests)
+        batch.next_token_chooser = batch.next_token_chooser.filter(keep_indices)
+        batch.max_seqlen = max(batch.input_lengths)
+        batch.input_ids = batch.input_ids[keep_indices]
+        batch.position_ids = batch.position_ids[keep_indices]
+        batch.all_input_ids_tensor = batch.all_input_ids_tensor[keep_indices, :max(batch.total_lengths)]
+        if new_size == 1:
+            batch.cu_seqlens = batch.cu_seqlens.new_tensor([0, batch.input_lengths[0]])
+        else:
+            # logical slot layout after re-packing: every kept sequence followed by its free slot
+            cu = batch.cu_seqlens[:new_size + 1].clone()
+            cu[1:] = batch.position_ids
+            cu[1:].add_(1)
+            batch.cu_seqlens = torch.cumsum(cu, dim=0, dtype=torch.int32)
+        batch.cu_seqlens_q = batch.cu_seqlens_q[:new_size + 1]
+        batch._rebuild_block_tables()
+        return batch
+
+
+class _DecodeGraph:
+    """Static buffers + captured HIP graph of one decode step for a (batch size, table width) pair."""
+
+    def __init__(self, lm: "FlashCausalLM", B: int, width: int):
+        dev = lm.device
+        self.input_ids = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.positions = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.block_tables = torch.zeros((B, width), dtype=torch.int32, device=dev)
+        self.slots = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.ctx = torch.ones(B, dtype=torch.int32, device=dev)
+        self.cu_q = torch.arange(B + 1, dtype=torch.int32, device=dev)
+        self.max_ctx = width * PAGE
+        self.num_splits = native.attn_num_splits(B, lm.num_kv_heads, lm.num_heads, 1, self.max_ctx)
+        self.lm = lm
+        self.graph = None
+        self.logits = self.ids = self.logprobs = None
+
+    def _step(self):
+        lm = self.lm
+        native.decode_slots(self.positions, self.block_tables, self.slots, self.ctx)
+        kv = KVArgs(cache=lm.kv_cache, block_tables=self.block_tables, ctx_lens=self.ctx, slots=self.slots,
+                    max_q_len=1, max_ctx=self.max_ctx, num_splits=self.num_splits)
+        logits = lm.model.forward(self.input_ids, self.positions, self.cu_q, self.max_ctx, None, kv)
+        ids, lps = native.argmax_logprob(logits)
+        return logits, ids, lps
+
+    def run(self, input_ids, position_ids, block_tables):
+        self.input_ids.copy_(input_ids, non_blocking=True)
+        self.positions.copy_(position_ids, non_blocking=True)
+        self.block_tables.copy_(block_tables, non_blocking=True)
+        if not self.lm.use_graphs:
+            return self._step()
+        if self.graph is None:
+            self._step()  # warm-up: sizes the workspaces, builds rope tables outside the capture
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.logits, self.ids, self.logprobs = self._step()
+            self.graph = g
+        self.graph.replay()
+        return self.logits, self.ids, self.logprobs
+
+
+class FlashCausalLM(Model):
+    def __init__(self, model_name: str, revision: Optional[str], deployment_framework: str, dtype: torch.dtype,
+                 quantize: Optional[str], model_config: Union[Any] = None, auto_model_class=None,
+                 max_sequence_length: Optional[int] = None, engine=None, kv_cache_pages: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise NotImplementedError("FlashCausalLM is only available on GPU")
+        if engine is None:
+            from tgis_amd.inference_engine import get_inference_engine_class
+            from tgis_amd.utils.hub import get_model_path
+
+            model_path = get_model_path(model_name, revision)
+            engine = get_inference_engine_class(deployment_framework)(
+                model_path, auto_model_class, dtype, quantize, model_config, max_sequence_length)
+        super().__init__(engine, dtype, max_sequence_length)
+        self.use_position_ids = True
+        tok = self.tokenizer
+        if tok is not None:
+            if getattr(self.config, "pad_token_id", None) is not None:
+                tok.pad_token_id = self.config.pad_token_id
+            elif tok.pad_token_id is None:
+                if getattr(self.config, "eos_token_id", None) is not None:
+                    tok.pad_token_id = self.config.eos_token_id
+                elif tok.eos_token_id is not None:
+                    tok.pad_token_id = tok.eos_token_id
+                else:
+                    tok.add_special_tokens({"pad_token": "[PAD]"})
+
+        inner = self.model.model
+        self.num_heads = inner.num_heads
+        self.num_kv_heads = inner.num_key_value_heads
+        self.head_size = inner.head_size
+        self.num_layers = len(inner.layers)
+        if hasattr(self.model, "post_init"):
+            self.model.post_init()
+        if kv_cache_pages is None:
+            kv_cache_pages = self._default_kv_pages()
+        self.kv_cache = PagedKVCache(self.num_layers, self.num_kv_heads, self.head_size, kv_cache_pages, dtype,
+                                     self.device)
+        # graphs with RCCL collectives inside are opt-in until exercised on a multi-GPU node
+        tp = engine.world_size if hasattr(engine, "world_size") else 1
+        self.use_graphs = USE_GRAPHS and (tp == 1 or os.getenv("TGIS_TP_GRAPHS", "false").lower() in ("1", "true"))
+        self._graphs = {}
+
+    def _default_kv_pages(self) -> int:
+        free, _total = torch.cuda.mem_get_info(self.device)
+        frac = float(os.getenv("TGIS_KV_CACHE_FRACTION", "0.85"))
+        per_page = self.num_layers * 2 * self.num_kv_heads * PAGE * self.head_size * 2
+        return max(64, int(free * frac) // per_page)
+
+    @property
+    def batch_type(self) -> Type[FlashCausalLMBatch]:
+        return FlashCausalLMBatch
+
+    # ---- the hot path -------------------------------------------------------------------------------------
+    def generate_token(self, batch: FlashCausalLMBatch, first: bool = False, for_concat: bool = False,
+                       ) -> Tuple[List[TokenInfo], Optional[List[InputTokens]], List[GenerateError], int]:
+        start_time = time.time_ns()
+        if first:
+            out, fused = self._prefill_forward(batch), None
+        else:
+            out, fused = self._decode_forward(batch)
+        forward_time_ns = time.time_ns() - start_time
+
+        if first:
+            generated_tokens, input_token_infos, decode_errors = self._process_prefill(batch, out)
+        else:
+            generated_tokens, decode_errors = self._process_decode(batch, out, fused)
+            input_token_infos = None
+
+        # logical slot bookkeeping of the reference: one more slot per sequence (:457-458)
+        batch.cu_seqlens.add_(batch.cu_seqlens_q)
+        batch.max_seqlen += 1
+        return generated_tokens, input_token_infos, decode_errors, forward_time_ns
+
+    def _prefill_forward(self, batch: FlashCausalLMBatch):
+        batch.allocate_pages(self.kv_cache)
+        lens = batch.input_lengths
+        slots = np.concatenate([
+            np.asarray(p, dtype=np.int64)[np.arange(l) // PAGE] * PAGE + np.arange(l) % PAGE
+            for p, l in zip(batch.pages, lens)]).astype(np.int32)
+        dev = self.device
+        kv = KVArgs(cache=self.kv_cache, block_tables=batch.block_tables,
+                    ctx_lens=torch.tensor(lens, dtype=torch.int32, device=dev),
+                    slots=torch.from_numpy(slots).to(dev, non_blocking=True),
+                    max_q_len=max(lens), max_ctx=max(lens), num_splits=1)
+        self._need_all_logits = any(r.details.input_toks for r in batch.requests)
+        lm_head_indices = None if self._need_all_logits else (batch.cu_seqlens[1:] - 1).long()
+        return self.model.forward(batch.input_ids, batch.position_ids.to(torch.int32), batch.cu_seqlens,
+                                  batch.max_seqlen, batch.inputs_embeds, kv, lm_head_indices)
+
+    def _decode_forward(self, batch: FlashCausalLMBatch):
+        key = (len(batch), batch.block_tables.shape[1])
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = _DecodeGraph(self, *key)
+        logits, ids, lps = g.run(batch.input_ids, batch.position_ids, batch.block_tables)
+        return logits, (ids, lps)
+
+    def _process_prefill(self, batch: FlashCausalLMBatch, out):
+        generated_tokens: List[TokenInfo] = []
+        input_token_infos: List[InputTokens] = []
+        decode_errors: List[GenerateError] = []
+        # position ids of the first generated token, set before input lengths are incremented
+        batch.position_ids = batch.position_ids.new_tensor(batch.input_lengths)
+        batch.input_ids = self._process_new_tokens(batch, out, generated_tokens, decode_errors, input_token_infos,
+                                                   True, None)
+        batch.inputs_embeds = None
+        batch.cu_seqlens_q = torch.arange(len(batch) + 1, device=self.device, dtype=torch.int32)
+        return generated_tokens, input_token_infos, decode_errors
+
+    def _process_decode(self, batch: FlashCausalLMBatch, out, fused):
+        generated_tokens: List[TokenInfo] = []
+        decode_errors: List[GenerateError] = []
+        batch.position_ids += 1  # used as the scatter index in _process_new_tokens
+        batch.input_ids = self._process_new_tokens(batch, out, generated_tokens, decode_errors, None, False, fused)
+        return generated_tokens, decode_errors
+
+    def _process_new_tokens(self, batch: FlashCausalLMBatch, out, generated_tokens: List[TokenInfo],
+                            decode_errors: List[GenerateError], input_token_infos: Optional[List[InputTokens]],
+                            prefill: bool, fused):
+        if prefill and self._need_all_logits:
+            logits = out[batch.cu_seqlens[1:] - 1, :]  # out is [sum(lengths), vocab]
+        else:
+            logits = out  # already one row per request
+
+        ntc = batch.next_token_chooser
+        simple = ntc.is_plain_greedy and not any(r.details.top_n_toks or r.details.ranks for r in batch.requests)
+        if simple:
+            # one kernel (already part of the decode graph), one device->host copy for the whole batch
+            next_token_ids, next_logprobs = fused if fused is not None else ntc.choose_greedy_fused(logits)
+            if not prefill:
+                next_token_ids = next_token_ids.clone()  # graph output buffer is reused next step
+        else:
+            next_token_ids, next_token_scores, next_token_logprobs = ntc(
+                input_ids=batch.all_input_ids_tensor[:, :batch.max_seqlen], scores=logits)
+
+        batch.all_input_ids_tensor.scatter_(dim=1, index=batch.position_ids[:, None], src=next_token_ids[:, None])
+
+        if simple:
+            ids_host = next_token_ids.tolist()
+            lps_host = next_logprobs.tolist() if any(ntc.return_logprobs) else None
+            for i, request in enumerate(batch.requests):
+                info = TokenInfo(request_id=request.id, token_id=ids_host[i])
+                if lps_host is not None and request.details.logprobs:
+                    info.logprob = lps_host[i]
+                generated_tokens.append(info)
+                if prefill and request.details.input_toks:
+                    self._append_input_tokens(batch, out, i, request, input_token_infos)
+                batch.input_lengths[i] += 1
+            return next_token_ids
+
+        for i, (request, next_token, scores, logprobs) in enumerate(
+                zip(batch.requests, next_token_ids, next_token_scores, next_token_logprobs)):
+            try:
+                tok_view = next_token.view(-1)
+                scores_view = scores.view(-1, scores.shape[-1])
+                logprobs_view = logprobs.view(-1, logprobs.shape[-1]) if request.details.logprobs else None
+                generated_tokens.append(get_token_info(request, scores_view, tok_view, logprobs_view))
+                if prefill and request.details.input_toks:
+                    self._append_input_tokens(batch, out, i, request, input_token_infos)
+            except Exception as e:
+                logging.exception(f"token decoding error for request #{request.id}")
+                decode_errors.append(GenerateError(request_id=request.id,
+                                                   message=f"Token decoding error: {str(e)}"))
+            batch.input_lengths[i] += 1
+        return next_token_ids
+
+    @staticmethod
+    def _append_input_tokens(batch, out, i, request, input_token_infos):
+        start = int(batch.cu_seqlens[i])
+        input_length = batch.input_lengths[i]
+        # the last position's logits predict the generated token, not an input token
+        logits = out[start:start + input_length - 1, :]
+        input_token_infos.append(get_input_tokens_info(request, batch.all_input_ids_tensor[i, :input_length], logits))

@@ -1,0 +1,250 @@
+"""Linear / embedding / head building blocks on the HIP kernels, with Megatron-style tensor parallelism.
+
+Mirrors utils/layers.py of the reference: `FastLinear` (:104-111), the `get_linear` quant registry
+(:172-203), `TensorParallelHead` (:215-277), `TensorParallelColumnLinear` (:280-297),
+`TensorParallelRowLinear` (all-reduce, :300-322), `TensorParallelEmbedding` (:325-357) and
+`PositionRotaryEmbedding` (:406-490); `Ex4bitLinearV2` mirrors utils/gptq/exllamav2.py:100-144.
+Every forward runs a kernel of libtgis_hip.so (decode-sized M) or, for prefill-sized M, a library GEMM
+on the same device; there is no CPU path."""
+import math
+from typing import List, Optional
+
+import torch
+import torch.distributed
+from torch.nn import functional as F
+
+from tgis_amd import native
+
+# rows up to which the weight-streaming MFMA kernels are used; above, dequant/hipBLASLt GEMM
+SKINNY_MAX_M = 64
+
+_WORKSPACES = {}
+
+
+def workspace(device) -> native.Workspace:
+    key = str(device)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = _WORKSPACES[key] = native.Workspace(64 << 20, device)
+    return ws
+
+
+class FastLinear:
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        self.weight = weight
+        self.bias = bias
+        self.prepared = native.DenseWeight(weight)
+        self.out_features, self.in_features = weight.shape
+
+    def forward(self, x: torch.Tensor, act: int = 0, out_f32: bool = False) -> torch.Tensor:
+        if x.shape[0] <= SKINNY_MAX_M:
+            return native.dense_gemm(x, self.prepared, workspace(x.device), bias=self.bias, out_f32=out_f32, act=act)
+        if act:
+            x = native.act_mul(x, self.in_features)
+        out = F.linear(x, self.weight, self.bias)
+        return out.float() if out_f32 else out
+
+    __call__ = forward
+
+
+class Ex4bitLinearV2:
+    """4-bit GPTQ linear.  Construction keeps the checkpoint tensors; `post_init` repacks them for the
+    kernels (the reference defers this the same way, server.py:347-354)."""
+    _temp_dq = {}
+
+    def __init__(self, qweight, qzeros, scales, g_idx, bias, bits, groupsize):
+        assert bits == 4
+        self.device = qweight.device
+        self.qweight, self.qzeros, self.scales = qweight, qzeros, scales
+        self.g_idx = g_idx.cpu() if g_idx is not None else None
+        self.bias = bias
+        self.bits, self.groupsize = bits, groupsize
+        self.height = qweight.shape[0] * 8
+        self.width = qweight.shape[1]
+        assert self.device.type == "cuda", "GPTQ requires the GPU (server.py:290-291)"
+        assert self.height % 32 == 0 and self.width % 32 == 0
+        self.q_handle: Optional[native.GptqWeight] = None
+
+    def post_init(self):
+        self.q_handle = native.GptqWeight(self.qweight, self.qzeros, self.scales, self.g_idx, self.bits,
+                                          self.groupsize)
+        self.qweight = self.qzeros = self.scales = None  # the prepared image replaces them
+
+    def _dequant_scratch(self) -> torch.Tensor:
+        key = (str(self.device), self.height, self.width)
+        buf = Ex4bitLinearV2._temp_dq.get(key)
+        if buf is None:
+            Ex4bitLinearV2._temp_dq.clear()  # one scratch at a time, like exllama's temp_dq
+            buf = Ex4bitLinearV2._temp_dq[key] = torch.empty((self.height, self.width), dtype=torch.float16,
+                                                             device=self.device)
+        return buf
+
+    def forward(self, x: torch.Tensor, act: int = 0) -> torch.Tensor:
+        if self.q_handle is None:
+            self.post_init()
+        if x.shape[0] <= SKINNY_MAX_M:
+            return native.gptq_gemm(x, self.q_handle, workspace(x.device), bias=self.bias, act=act)
+        # prefill-sized M: dequantise once into scratch, then a library GEMM (exllamav2.py:87 "M > 50")
+        if act:
+            x = native.act_mul(x, self.height)
+        if self.q_handle.perm is not None:
+            x = x.index_select(1, self.q_handle.perm.long())
+        w = self._dequant_scratch()
+        native._check(native.load_library().tgis_gptq_dequant_f16(
+            self.q_handle.image.data_ptr(), w.data_ptr(), self.height, self.width, self.q_handle.groups,
+            native._stream()), "tgis_gptq_dequant_f16")
+        out = torch.matmul(x, w)
+        if self.bias is not None:
+            out.add_(self.bias)
+        return out
+
+    __call__ = forward
+
+
+def get_linear(weight, bias, quantize):
+    if quantize is None:
+        return FastLinear(weight, bias)
+    if quantize == "gptq":
+        try:
+            qweight, qzeros, scales, g_idx, bits, groupsize, _use = weight
+        except Exception:
+            raise NotImplementedError("The passed weight is not `gptq` compatible, loader needs to be updated.")
+        return Ex4bitLinearV2(qweight, qzeros, scales, g_idx, bias, bits, groupsize)
+    raise NotImplementedError(f"Quantization `{quantize}` is not implemented yet.")
+
+
+class SuperLayer:
+    def __init__(self, linear):
+        self.linear = linear
+
+    def forward(self, x, **kw):
+        return self.linear.forward(x, **kw)
+
+    __call__ = forward
+
+
+class TensorParallelHead(SuperLayer):
+    def __init__(self, linear, process_group, should_gather: bool):
+        super().__init__(linear)
+        self.process_group = process_group
+        self.should_gather = should_gather
+
+    @staticmethod
+    def load(config, prefix: str, weights):
+        if weights.process_group.size() > 1:
+            try:
+                weight = weights.get_sharded(f"{prefix}.weight", dim=0)
+                should_gather = True
+            except AssertionError:
+                # vocab not divisible by the number of shards: every rank keeps the full head
+                weight = weights.get_tensor(f"{prefix}.weight")
+                should_gather = False
+        else:
+            weight = weights.get_tensor(f"{prefix}.weight")
+            should_gather = False
+        # GPTQ doesn't quantize heads (nor embeddings)
+        return TensorParallelHead(get_linear(weight, bias=None, quantize=None), weights.process_group, should_gather)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """fp32 logits [T, V]; vocab shards are gathered so every rank holds identical logits."""
+        local = self.linear.forward(x, out_f32=True)
+        if not self.should_gather:
+            return local
+        world = self.process_group.size()
+        # gather [V/tp, T] blocks so the result is a plain transpose view (layers.py:244-269)
+        gather_in = local.t().contiguous()
+        world_out = torch.empty((gather_in.shape[0] * world, gather_in.shape[1]), dtype=local.dtype,
+                                device=local.device)
+        torch.distributed.all_gather_into_tensor(world_out, gather_in, group=self.process_group)
+        return world_out.t()
+
+    __call__ = forward
+
+
+class TensorParallelColumnLinear(SuperLayer):
+    @classmethod
+    def load(cls, config, prefix: str, weights, bias: bool):
+        return cls.load_multi(config, [prefix], weights, bias, dim=0)
+
+    @classmethod
+    def load_multi(cls, config, prefixes: List[str], weights, bias: bool, dim: int):
+        weight = weights.get_multi_weights_col(prefixes, quantize=config.quantize, dim=dim)
+        if bias:
+            b = [weights.get_sharded(f"{p}.bias", dim=0) for p in prefixes]
+            bias = torch.cat(b, dim=dim)
+        else:
+            bias = None
+        return cls(get_linear(weight, bias, config.quantize))
+
+
+class TensorParallelRowLinear(SuperLayer):
+    def __init__(self, linear, process_group):
+        super().__init__(linear)
+        self.process_group = process_group
+
+    @classmethod
+    def load(cls, config, prefix: str, weights, bias: bool):
+        weight = weights.get_multi_weights_row(prefix, quantize=config.quantize)
+        if bias and weights.process_group.rank() == 0:
+            bias = weights.get_tensor(f"{prefix}.bias")  # bias only on the first rank
+        else:
+            bias = None
+        return cls(get_linear(weight, bias, config.quantize), process_group=weights.process_group)
+
+    def forward(self, x: torch.Tensor, **kw) -> torch.Tensor:
+        out = self.linear.forward(x, **kw)
+        if self.process_group.size() > 1:
+            torch.distributed.all_reduce(out, group=self.process_group)
+        return out
+
+    __call__ = forward
+
+
+class TensorParallelEmbedding:
+    def __init__(self, prefix: str, weights, reduce=True):
+        self.weight = weights.get_partial_sharded(f"{prefix}.weight", dim=0).contiguous()
+        num_embeddings = weights.get_shape(f"{prefix}.weight")[0]
+        self.process_group = weights.process_group
+        world_size = self.process_group.size()
+        rank = self.process_group.rank()
+        block_size = num_embeddings // world_size
+        self.min_id = rank * block_size
+        self.max_id = min(num_embeddings, (rank + 1) * block_size)
+        self.reduce = reduce
+
+    def forward(self, input_ids: torch.Tensor, positions=None, pos_table=None) -> torch.Tensor:
+        # ids outside [min_id, max_id) read the null (zero) row, then shards are summed (layers.py:346-357)
+        out = native.embedding(input_ids, self.weight, positions=positions, pos_table=pos_table,
+                               id_offset=self.min_id)
+        if self.reduce and self.process_group.size() > 1:
+            torch.distributed.all_reduce(out, group=self.process_group)
+        return out
+
+    __call__ = forward
+
+
+class PositionRotaryEmbedding:
+    """cos/sin caches: inv_freq and freqs in fp32, tables cast to the model dtype (layers.py:419-451)."""
+
+    def __init__(self, inv_freq: torch.Tensor, scaling_factor: float = 1.0):
+        self.inv_freq = inv_freq
+        self.scaling_factor = scaling_factor
+        self._seq_len_cached = 0
+        self._cos_cached = None
+        self._sin_cached = None
+
+    @classmethod
+    def static(cls, dim, base, device, scaling_factor=1.0):
+        inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2, device=device, dtype=torch.float32) / dim))
+        return cls(inv_freq, scaling_factor)
+
+    def tables(self, dtype, device, seqlen: int):
+        if seqlen > self._seq_len_cached or self._cos_cached.device != device or self._cos_cached.dtype != dtype:
+            self._seq_len_cached = seqlen
+            t = torch.arange(seqlen, device=device, dtype=self.inv_freq.dtype)
+            if self.scaling_factor != 1.0:
+                t = t / self.scaling_factor
+            freqs = torch.outer(t, self.inv_freq.to(device=t.device))
+            self._cos_cached = torch.cos(freqs).to(dtype).contiguous()
+            self._sin_cached = torch.sin(freqs).to(dtype).contiguous()
+        return self._cos_cached, self._sin_cached
