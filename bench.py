@@ -1,0 +1,261 @@
+#!/usr/bin/env python
+"""Decode-throughput benchmark of the hot path: FlashCausalLM.generate_token on synthetic fixed-length batches.
+
+Metric (BASELINE.json): decode tokens/s (+ p50 step latency), Llama-2-7B int4 GPTQ g128, batch 32, mean context
+1024, fp16 activations.  A "step" is one NextToken-equivalent call: generate_token(batch)
+including greedy sampling and the one device->host copy of the token ids.  Weights are seeded synthetic tensors
+at the real shapes (no checkpoints offline); KV is produced by a real prefill of the same model before timing.
+
+  python bench.py --gpus 1 --steps 32 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W          # tensor parallel over RCCL, same global batch
+
+Rank 0 prints ONE JSON line with the contract fields plus "roofline" (dominant kernel = paged decode attention,
+algorithmic KV bytes / HIP-event launch duration) and "cpu_baseline" (fp32 CPU oracle on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "text-generation-inference_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+CONFIGS = {
+    # name: (llama config kwargs, quantize, dtype, batch, mean ctx)
+    "llama2-7b-gptq": (dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
+                            num_attention_heads=32, num_key_value_heads=32, rms_norm_eps=1e-5), "gptq", "float16", 32,
+                       1024),
+    "tinyllama-1.1b": (dict(vocab_size=32000, hidden_size=2048, intermediate_size=5632, num_hidden_layers=22,
+                            num_attention_heads=32, num_key_value_heads=4, rms_norm_eps=1e-5), None, "bfloat16", 16, 512),
+    "llama-tiny-gptq": (dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                             num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5), "gptq", "float16", 4, 64),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def algorithmic_bytes_per_step(cfg, quantize, B, ctx_mean, tp, groupsize=128):
+    """W_q + W_sz + W_dense + KV_read + KV_write per rank per decode step."""
+    E, I, L, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.vocab_size
+    H, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    D = E // H
+    mats = [(E, (H + 2 * Hkv) * D), (E, E), (E, 2 * I), (I, E)]
+    params = sum(k * n for k, n in mats)
+    if quantize == "gptq":
+        w = L * (params / 2 + sum((k / groupsize) * n * 2.5 for k, n in mats)) / tp
+    else:
+        w = L * params * 2 / tp
+    head = V * E * 2 / tp
+    kv_tok = L * 2 * (Hkv / tp if Hkv >= tp else 1) * D * 2
+    kv_read = B * ctx_mean * kv_tok
+    kv_write = B * kv_tok
+    return {"weights": w, "head": head, "kv_read": kv_read, "kv_write": kv_write,
+            "total": w + head + kv_read + kv_write}
+
+
+def cpu_baseline(cfg, quantize, B, ctx, groupsize=128):
+    """The CPU oracle's arithmetic (oracle/ops_ref.py + oracle/llama_ref.py: the fp32 restatement of the reference's
+    CPU causal_lm forward) timed on this host for ONE decoder layer of one decode step at the full batch and
+    context, batched over sequences, then scaled to all layers (+ measured lm_head).  GPTQ weights are dequantised
+    to fp32 first, exactly what the reference must do on CPU (server.py:290-291).  A reported baseline only."""
+    from oracle import ops_ref
+
+    threads = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(threads)
+    E, I, H = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
+    Hkv = cfg.num_key_value_heads
+    D = E // H
+    g = torch.Generator().manual_seed(0)
+
+    def weight(k, n):
+        if quantize == "gptq":
+            qw, qz, sc, gi = ops_ref.make_gptq_tensors(k, n, groupsize, seed=k + n)
+            return ops_ref.gptq_dequant(qw, qz, sc, gi, groupsize)
+        return torch.randn(k, n, generator=g) * 0.02
+
+    wq, wo, wgu, wd = weight(E, (H + 2 * Hkv) * D), weight(E, E), weight(E, 2 * I), weight(I, E)
+    norm_w = torch.ones(E)
+    Kc = torch.randn(B, Hkv, ctx, D, generator=g)
+    Vc = torch.randn(B, Hkv, ctx, D, generator=g)
+    x = torch.randn(B, E, generator=g)
+    cos, sin = ops_ref.rope_tables(D, 10000.0, ctx, torch.float32)
+    pos = torch.full((B,), ctx - 1, dtype=torch.int64)
+
+    def layer(x, residual):
+        h, residual = ops_ref.rmsnorm_residual(x, residual, norm_w, cfg.rms_norm_eps)
+        qkv = h @ wq
+        q = ops_ref.apply_rope(qkv[:, :H * D].reshape(B, H, D), cos[pos], sin[pos])
+        k = ops_ref.apply_rope(qkv[:, H * D:(H + Hkv) * D].reshape(B, Hkv, D), cos[pos], sin[pos])
+        v = qkv[:, (H + Hkv) * D:].reshape(B, Hkv, D)
+        Kc[:, :, -1] = k
+        Vc[:, :, -1] = v
+        G = H // Hkv
+        qg = q.reshape(B, Hkv, G, D)
+        s = torch.einsum("bhgd,bhtd->bhgt", qg, Kc) * (D ** -0.5)
+        p = torch.softmax(s, dim=-1)
+        o = torch.einsum("bhgt,bhtd->bhgd", p, Vc).reshape(B, H * D)
+        h2, residual = ops_ref.rmsnorm_residual(o @ wo, residual, norm_w, cfg.rms_norm_eps)
+        return ops_ref.silu_mul(h2 @ wgu, I) @ wd, residual
+
+    layer(x, x)  # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 20 and (reps < 2 or time.perf_counter() - t0 < 10.0):
+        layer(x, x)
+        reps += 1
+    t_layer = (time.perf_counter() - t0) / reps
+    head_w = torch.randn(E, cfg.vocab_size, generator=g)
+    t1 = time.perf_counter()
+    ops_ref.greedy(x @ head_w)
+    t_head = time.perf_counter() - t1
+    step_s = t_layer * cfg.num_hidden_layers + t_head
+    return {"value": round(B / step_s, 2), "unit": "tokens/s", "cores": threads, "kind": "port",
+            "ms_per_step": round(step_s * 1e3, 1),
+            "sample": f"one decoder layer of one decode step at B={B}, ctx={ctx}, fp32, {reps} repetitions, "
+                      f"x{cfg.num_hidden_layers} layers + lm_head/greedy"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="llama2-7b-gptq", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--ctx", type=int, default=None, help="mean context length over the timed steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.getenv("RANK", "0"))
+    world = int(os.getenv("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
+
+    from tgis_amd import native
+    from tgis_amd.inference_engine.synthetic import InferenceEngine, llama_tensors
+    from tgis_amd.models.custom_modeling.flash_llama_modeling import LlamaConfig
+    from tgis_amd.models.flash_causal_lm import FlashCausalLM
+    from tgis_amd.testing import SyntheticTokenizer, make_batch_pb
+    from tgis_amd.utils.kv_cache import PagedKVCache
+
+    kw, quantize, dtype_s, B, ctx_mean = CONFIGS[args.config]
+    B = args.batch or B
+    ctx_mean = args.ctx or ctx_mean
+    cfg = LlamaConfig(**kw)
+    dtype = getattr(torch, dtype_s)
+    K, W = args.steps, args.warmup
+    # context grows by one per step; centre the timed steps on ctx_mean
+    L_in = max(1, ctx_mean - W - K // 2 - 1)
+    total_len = L_in + W + K + 8
+
+    device = torch.device("cuda", rank % torch.cuda.device_count())
+    torch.cuda.set_device(device)
+    tensors = llama_tensors(cfg, quantize, seed=1234, device=device, dtype=dtype)
+    tok = SyntheticTokenizer(cfg.vocab_size)
+    eng = InferenceEngine(tensors, cfg, dtype, quantize, tokenizer=tok)
+    del tensors
+    pages = B * PagedKVCache.pages_for(total_len) + 8
+    lm = FlashCausalLM("synthetic", None, "synthetic", dtype, quantize, engine=eng, kv_cache_pages=pages)
+    torch.cuda.empty_cache()
+    tp = eng.world_size
+    graphs_used = bool(lm.use_graphs)
+
+    def sync():
+        torch.cuda.synchronize()
+        if tp > 1:
+            torch.distributed.barrier()
+
+    def fresh_batch():
+        pb = make_batch_pb([L_in] * B, max_new=W + K + 8)
+        batch, errs = lm.batch_type.from_pb(pb, tok, lm.dtype, lm.device, lm.word_embeddings, None, True)
+        assert not errs
+        lm.generate_token(batch, first=True)  # prefill (untimed): fills the KV pages
+        return batch
+
+    with lm.context_manager():
+        batch = fresh_batch()
+        for _ in range(W):
+            lm.generate_token(batch)
+        sync()
+        step_ms = []
+        t0 = time.perf_counter()
+        for _ in range(K):
+            ts = time.perf_counter()
+            lm.generate_token(batch)
+            step_ms.append((time.perf_counter() - ts) * 1e3)
+        sync()
+        elapsed = time.perf_counter() - t0
+        if tp > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        ctx_timed_mean = L_in + 1 + W + (K - 1) / 2.0  # keys attended per step, averaged over the timed steps
+
+        roofline = None
+        if not args.no_roofline:  # every rank runs it (the forward contains collectives when tp > 1)
+            # Instrumented pass over the same workload: eager launches (HIP events cannot bracket nodes of a
+            # replayed graph), event pairs recorded by libtgis_hip.so on the launch stream around every attention
+            # launch.  Its own timed region of K steps, same batch shape and context range.
+            batch.release()
+            del batch
+            lm.use_graphs = False
+            batch = fresh_batch()
+            for _ in range(W):
+                lm.generate_token(batch)
+            sync()
+            native.timing_reset()
+            native.timing_enable(True)
+            for _ in range(K):
+                lm.generate_token(batch)
+            sync()
+            native.timing_enable(False)
+            n_attn, ms_attn = native.timing_read(native.OP_ATTN)
+            n_gemm, ms_gemm = native.timing_read(native.OP_GPTQ_GEMM if quantize == "gptq" else native.OP_DENSE_GEMM)
+            Hkv_rank = max(1, cfg.num_key_value_heads // tp)
+            D = cfg.hidden_size // cfg.num_attention_heads
+            bytes_per_launch = B * ctx_timed_mean * 2 * Hkv_rank * D * 2 + B * 2 * Hkv_rank * D * 2
+            avg_s = ms_attn * 1e-3 / max(n_attn, 1)
+            achieved = bytes_per_launch / avg_s / 1e9
+            roofline = {"bound": "hbm", "kernel": "attn_paged_kernel (decode)", "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": None, "launches": int(n_attn), "avg_launch_us": round(avg_s * 1e6, 2),
+                        "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                        "gemm_launches": int(n_gemm), "gemm_avg_launch_us": round(ms_gemm * 1e3 / max(n_gemm, 1), 2)}
+
+    toks_per_s = B * K / elapsed
+    ab = algorithmic_bytes_per_step(cfg, quantize, B, ctx_timed_mean, tp)
+    step_roof_ms = ab["total"] / (HBM_PEAK_GBS * 1e9) * 1e3
+    out = {
+        "metric": "decode tokens/sec (Llama-7B int4 GPTQ, batch 32, ctx 1024) + p50 step latency",
+        "value": round(toks_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(elapsed / K * 1e3, 4), "p50_step_ms": round(sorted(step_ms)[len(step_ms) // 2], 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16",
+        "data": "synthetic (seeded weights at the real shapes; KV from a real prefill of seeded token ids)",
+        "config": {"workload": f"{args.config} decode, B={B}, mean ctx {ctx_timed_mean:.1f} "
+                               f"(L_in={L_in}, {W} warm-up + {K} timed steps), greedy",
+                   "global_batch": B, "seq_len": int(round(ctx_timed_mean)), "parallelism": f"tp{tp}",
+                   "weights": "int4 GPTQ g128" if quantize == "gptq" else dtype_s, "hip_graph": graphs_used},
+        "step_roofline": {"algorithmic_bytes_per_step": int(ab["total"]), "ms_at_hbm_peak": round(step_roof_ms, 4),
+                          "frac_of_hbm_peak": round(step_roof_ms / (elapsed / K * 1e3), 4)},
+    }
+    if roofline is not None:
+        out["roofline"] = roofline
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(cfg, quantize, B, int(round(ctx_timed_mean)))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if tp > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
