@@ -1,0 +1,83 @@
+"""CPU: FlashCausalLMBatch host bookkeeping (no kernels involved): from_pb tensors, page ownership through
+concatenate / prune / release, and the reference's logical cu_seqlens arithmetic
+(models/flash_causal_lm.py:67-194,196-285,290-353)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.fixture_utils import FixtureTokenizer, prompt_text
+from tgis_amd.models.flash_causal_lm import FlashCausalLMBatch
+from tgis_amd.models.model import Model
+from tgis_amd.pb import generate_pb2 as pb2
+from tgis_amd.utils.kv_cache import OutOfPages, PagedKVCache
+
+CPU = torch.device("cpu")
+
+
+def _pb(prompts, max_new, first_id=0, batch_id=0, truncate_to=None):
+    reqs = []
+    for i, p in enumerate(prompts):
+        n = len(p) if truncate_to is None else truncate_to[i]
+        reqs.append(pb2.Request(id=first_id + i, inputs=prompt_text(p), input_length=n, truncate=truncate_to is not None,
+                                max_output_length=max_new))
+    return pb2.Batch(id=batch_id, requests=reqs)
+
+
+def _batch(prompts, max_new, **kw):
+    tok = FixtureTokenizer(256)
+    b, errs = FlashCausalLMBatch.from_pb(_pb(prompts, max_new, **kw), tok, torch.float16, CPU, None, None, True)
+    assert not errs
+    return b
+
+
+def test_from_pb_concatenates_without_padding():
+    prompts = [[5, 6, 7], [9], [11, 12, 13, 14, 15]]
+    b = _batch(prompts, 4)
+    assert b.input_ids.tolist() == [5, 6, 7, 9, 11, 12, 13, 14, 15]
+    assert b.position_ids.tolist() == [0, 1, 2, 0, 0, 1, 2, 3, 4]
+    assert b.cu_seqlens.tolist() == [0, 3, 4, 9] and b.cu_seqlens.dtype == torch.int32
+    assert b.max_seqlen == 5 and b.input_lengths == [3, 1, 5] and b.total_lengths == [7, 5, 9]
+    assert b.all_input_ids_tensor.shape == (3, 9)
+    assert b.all_input_ids_tensor[1].tolist() == [9] + [0] * 8  # pad-filled
+    assert b.past_key_values is None and b.pages is None and len(b) == 3 and b.get_id() == 0
+
+
+def test_from_pb_left_truncation_and_bos():
+    tok = FixtureTokenizer(256)
+    tok.add_bos_token = True
+    b, _ = FlashCausalLMBatch.from_pb(_pb([[5, 6, 7, 8, 9]], 2, truncate_to=[3]), tok, torch.float16, CPU, None, None)
+    assert b.input_ids.tolist() == [1, 8, 9]  # last 3 tokens kept, BOS re-inserted in front
+
+
+def test_page_ownership_concat_prune_release():
+    cache = PagedKVCache(2, 2, 64, 16, torch.float16, CPU)
+    a = _batch([[5] * 30, [6] * 3], 40, batch_id=1)          # 70 and 43 tokens -> 3 + 2 pages
+    a.allocate_pages(cache)
+    assert [len(p) for p in a.pages] == [3, 2] and cache.free_pages == 11
+    assert a.block_tables.shape == (2, 8) and a.block_tables.dtype == torch.int32
+    b = _batch([[7] * 10], 5, first_id=2, batch_id=2)
+    b.allocate_pages(cache)
+    a.cu_seqlens_q = torch.arange(3, dtype=torch.int32)
+    b.cu_seqlens_q = torch.arange(2, dtype=torch.int32)
+    m = FlashCausalLMBatch.concatenate([a, b])
+    assert a.pages is None and b.pages is None and [len(p) for p in m.pages] == [3, 2, 1]
+    assert m.batch_id == 1 and [r.id for r in m.requests] == [0, 1, 2] and cache.free_pages == 10
+    assert m.cu_seqlens.tolist() == [0, 30, 33, 43]
+    # prune the middle request: its pages return to the pool, logical cu_seqlens are re-packed
+    m.position_ids = torch.tensor([30, 3, 10])
+    kept = FlashCausalLMBatch.prune(m, [1])
+    assert kept is m and [r.id for r in m.requests] == [0, 2] and cache.free_pages == 12
+    assert m.cu_seqlens.tolist() == [0, 31, 42]  # cumsum(position + 1): each kept run plus its free slot
+    assert FlashCausalLMBatch.prune(m, []) is m
+    assert FlashCausalLMBatch.prune(m, [0, 2]) is None and cache.free_pages == 16
+    c = _batch([[1] * 600], 10)
+    with pytest.raises(OutOfPages):
+        c.allocate_pages(cache)
+    assert cache.free_pages == 16  # nothing leaked by the failed allocation
+
+
+def test_get_indices_to_keep_merge():
+    reqs = [pb2.Request(id=i) for i in (2, 3, 5, 8, 13)]
+    assert Model.get_indices_to_keep(reqs, [3, 8]) == [0, 2, 4]
+    assert Model.get_indices_to_keep(reqs, [1, 2, 13, 99]) == [1, 2, 3]
+    assert Model.get_indices_to_keep(reqs, []) == [0, 1, 2, 3, 4]

@@ -61,7 +61,7 @@ class Ex4bitLinearV2:
         self.bits, self.groupsize = bits, groupsize
         self.height = qweight.shape[0] * 8
         self.width = qweight.shape[1]
-        assert self.device.type == "cuda", "GPTQ requires the GPU (server.py:290-291)"
+        # (no device check here: native.GptqWeight refuses tensors that are not on the GPU — server.py:290-291)
         assert self.height % 32 == 0 and self.width % 32 == 0
         self.q_handle: Optional[native.GptqWeight] = None
 
