@@ -90,6 +90,16 @@ int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepared, const v
                        const int32_t* perm, void* out, int64_t ldo, int64_t M, int64_t K, int64_t N,
                        int64_t groups, int act, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Deferred-reduce variant for M <= 32: instead of the f16 result, the S split-K partial sums are left in
+ * `slabs` as fp32 [S][32][ld] (ld = N rounded up to 32, returned in *slab_ld; S in *num_slabs, >= 1) for a
+ * consumer that sums them in its prologue (tgis_rmsnorm_residual_partial / tgis_rope_kv_write_partial), which
+ * removes the reduce launch.  The consumer rounds the sum (+bias) to f16 first, so results are bit-identical to
+ * tgis_gptq_gemm_f16 followed by the plain consumer.  slabs must hold tgis_gptq_gemm_partial_bytes(K,N) bytes. */
+int64_t tgis_gptq_gemm_partial_bytes(int64_t K, int64_t N);
+int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void* prepared, const int32_t* perm, int64_t M,
+                               int64_t K, int64_t N, int64_t groups, int act, float* slabs, int64_t slabs_bytes,
+                               int* num_slabs, int64_t* slab_ld, void* stream);
+
 /* Full dequantisation to a dense f16 [K,N] matrix (row-major), the "temp_dq" path the reference
  * uses for M > 50 before a library GEMM (exllamav2.py:65-66,87). */
 int tgis_gptq_dequant_f16(const void* prepared, void* w_out, int64_t K, int64_t N, int64_t groups,
@@ -113,6 +123,11 @@ int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared, const void
 int tgis_rmsnorm_residual(const void* x, const void* residual, const void* weight, void* y,
                           void* res_out, int64_t rows, int64_t hidden, float eps, int dtype,
                           void* stream);
+/* Same as tgis_rmsnorm_residual with x given as split-K partial sums: x = f16(sum_s slabs[s][row][:] (+ bias)).
+ * rows <= 32. */
+int tgis_rmsnorm_residual_partial(const float* slabs, int num_slabs, int64_t slab_ld, const void* bias,
+                                  const void* residual, const void* weight, void* y, void* res_out, int64_t rows,
+                                  int64_t hidden, float eps, int dtype, void* stream);
 int tgis_layernorm_residual(const void* x, const void* residual, const void* weight, const void* bias,
                             void* y, void* res_out, int64_t rows, int64_t hidden, float eps,
                             int dtype, void* stream);
@@ -127,6 +142,13 @@ int tgis_layernorm_residual(const void* x, const void* residual, const void* wei
 int tgis_rope_kv_write(void* qkv, int64_t ld_qkv, const void* cos, const void* sin,
                        const int32_t* positions, const int32_t* slots, void* k_pool, void* v_pool,
                        int64_t T, int H, int Hkv, int D, int rot_dim, int dtype, void* stream);
+
+/* Same with the qkv activation given as split-K partial sums (T <= 32): qkv_out[T, ld_qkv] receives
+ * f16(sum_s slabs[s] (+ bias)) with q,k rotated; k,v go to the cache. */
+int tgis_rope_kv_write_partial(const float* slabs, int num_slabs, int64_t slab_ld, const void* bias, void* qkv_out,
+                               int64_t ld_qkv, const void* cos, const void* sin, const int32_t* positions,
+                               const int32_t* slots, void* k_pool, void* v_pool, int64_t T, int H, int Hkv, int D,
+                               int rot_dim, int dtype, void* stream);
 
 /* ---- paged attention, prefill and decode (replaces flash_attn_2_cuda.varlen_fwd,
  *      utils/flash_attn.py:43-78) ---------------------------------------------------------------- */

@@ -85,6 +85,7 @@ def _rope_kv_write(qkv, cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, r
     store = _POOLS.setdefault(k_pool.data_ptr(), {})
     for t in range(T):
         store[int(slots[t])] = (k[t].clone(), v[t].clone())
+    return qkv
 
 
 def _attn_paged(q, ld_q, k_pool, v_pool, block_tables, ctx_lens, cu_q, out, B, H, Hkv, D, max_q_len, max_ctx, scale,
@@ -136,5 +137,6 @@ def install(monkeypatch):
         rope_kv_write=_rope_kv_write, attn_paged=_attn_paged, embedding=_embedding, decode_slots=_decode_slots,
         argmax_logprob=_argmax_logprob, attn_num_splits=lambda *a: 1, attn_workspace_bytes=lambda *a: 0,
         act_mul=lambda gu, I, out=None: ops_ref.silu_mul(gu, I).to(gu.dtype),
+        gptq_gemm_partial=lambda x, w, bias=None, act=0: _gptq_gemm(x, w, None, bias=bias, act=act),
     ).items():
         monkeypatch.setattr(native, name, fn)

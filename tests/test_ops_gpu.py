@@ -286,3 +286,49 @@ def test_argmax_logprob(nat, gpu_device, dtype):
     assert torch.equal(ids.cpu(), wi), "greedy token ids must be bit-exact"
     assert int(ids[5]) == 7
     _close(lp, wl, rtol=1e-5, atol=1e-5, what="logprob")
+
+
+# ---- deferred split-K reduce: GEMM leaves fp32 slabs, the consumer kernel finishes the sum -----------------------
+@pytest.mark.parametrize("M,K,N", [(32, 4096, 4096), (5, 11008, 4096), (1, 256, 64)])
+def test_gptq_partial_then_rmsnorm_is_bit_identical_to_unfused(nat, gpu_device, M, K, N):
+    gs = 128 if K % 128 == 0 else 64
+    qw, qz, sc, gi = ops_ref.make_gptq_tensors(K, N, gs, seed=K + N)
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, K, generator=g) * 0.5).half().to(gpu_device)
+    res = torch.randn(M, N, generator=g).half().to(gpu_device)
+    bias = (torch.randn(N, generator=g) * 0.1).half().to(gpu_device)
+    wn = (1 + 0.1 * torch.randn(N, generator=g)).half().to(gpu_device)
+    w = nat.GptqWeight(torch.from_numpy(qw).to(gpu_device), torch.from_numpy(qz).to(gpu_device),
+                       torch.from_numpy(sc).to(gpu_device), None, 4, gs)
+    ws = nat.Workspace(w.workspace_bytes(M), gpu_device)
+    y0, r0 = nat.rmsnorm_residual(nat.gptq_gemm(x, w, ws, bias=bias), res, wn, 1e-5)
+    part = nat.gptq_gemm_partial(x, w, bias=bias)
+    if K >= 4096:
+        assert part.S > 1, "this shape is meant to exercise a real split"
+    y1, r1 = nat.rmsnorm_residual(part, res, wn, 1e-5)
+    assert torch.equal(y0, y1) and torch.equal(r0, r1)
+    want_y, want_r = ops_ref.rmsnorm_residual(ops_ref.gptq_linear(x.cpu(), qw, qz, sc, gi, gs, bias.cpu()).half(),
+                                              res.cpu(), wn.cpu(), 1e-5)
+    _close(y1, want_y, rtol=4e-3, atol=4e-3, what="partial+rmsnorm vs oracle")
+
+
+def test_gptq_partial_then_rope_kv_is_bit_identical_to_unfused(nat, gpu_device):
+    H, Hkv, D, K, B = 8, 8, 128, 4096, 7
+    N = (H + 2 * Hkv) * D
+    qw, qz, sc, gi = ops_ref.make_gptq_tensors(K, N, 128, seed=17)
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(B, K, generator=g) * 0.5).half().to(gpu_device)
+    w = nat.GptqWeight(torch.from_numpy(qw).to(gpu_device), torch.from_numpy(qz).to(gpu_device),
+                       torch.from_numpy(sc).to(gpu_device), None, 4, 128)
+    ws = nat.Workspace(w.workspace_bytes(B), gpu_device)
+    cos, sin = ops_ref.rope_tables(D, 10000.0, 64, torch.float16)
+    cos, sin = cos.to(gpu_device), sin.to(gpu_device)
+    pos = torch.tensor([3, 0, 31, 32, 17, 5, 63], dtype=torch.int32, device=gpu_device)
+    slots = torch.tensor([3, 32, 95, 96, 145, 165, 255], dtype=torch.int32, device=gpu_device)
+    pools = [torch.zeros((8, Hkv, 32 * D), dtype=torch.float16, device=gpu_device) for _ in range(4)]
+    q0 = nat.rope_kv_write(nat.gptq_gemm(x, w, ws), cos, sin, pos, slots, pools[0], pools[1], H, Hkv, D, D)
+    part = nat.gptq_gemm_partial(x, w)
+    assert part.S > 1
+    q1 = nat.rope_kv_write(part, cos, sin, pos, slots, pools[2], pools[3], H, Hkv, D, D)
+    assert torch.equal(q0, q1) and torch.equal(pools[0], pools[2]) and torch.equal(pools[1], pools[3])
+    assert pools[0].abs().sum() > 0

@@ -91,4 +91,30 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Sum of S split-K slabs for 8 consecutive columns: all loads are issued before the first add (a runtime-trip
+// loop would serialise one L2 round trip per slab).  stride = elements between slabs.
+__device__ __forceinline__ void sum_slabs8(const float* sp, int64_t stride, int S, f32x4& lo, f32x4& hi) {
+    constexpr int MAXS = 8;
+    f32x4 l[MAXS], h[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        const float* q = sp + (int64_t)min(s, S - 1) * stride;
+        l[s] = *reinterpret_cast<const f32x4*>(q);
+        h[s] = *reinterpret_cast<const f32x4*>(q + 4);
+    }
+    lo = l[0];
+    hi = h[0];
+#pragma unroll
+    for (int s = 1; s < MAXS; ++s) {
+        if (s < S) {
+            lo += l[s];
+            hi += h[s];
+        }
+    }
+    for (int s = MAXS; s < S; ++s) {
+        lo += *reinterpret_cast<const f32x4*>(sp + (int64_t)s * stride);
+        hi += *reinterpret_cast<const f32x4*>(sp + (int64_t)s * stride + 4);
+    }
+}
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -126,7 +126,8 @@ struct GemmArgs {
     int KR;        // k-range per block (multiple of 256)
     int S;         // global k splits
     int NT, KS;
-    float* slabs;  // [Mslabs][S][32][NT*32] f32 partial sums (S > 1)
+    float* slabs;  // [Mslabs][S][32][NT*32] f32 partial sums (S > 1 or partial mode)
+    int partial;   // 1: always leave fp32 slabs (deferred reduce), never write `out`
     int dbg;       // tuning hook (TGIS_GPTQ_DBG): 1 = restage x chunk 0 only, 2 = reload weight step 0 only
 };
 
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(64 * WN) void gptq_gemm_kernel(GemmArgs a) {
     if (nt_raw >= a.NT) return;
     const f32x16 acc = (accs[0] + accs[1]) + (accs[2] + accs[3]);
     const int n = nt * 32 + (lane & 31);
-    if (a.S == 1) {
+    if (a.S == 1 && !a.partial) {
         const float bv = (a.bias && n < a.N) ? (float)a.bias[n] : 0.f;
         if (n < a.N) {
 #pragma unroll
@@ -451,28 +452,13 @@ extern "C" int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t 
     return 4096 + slab_bytes(M, N, pl.S);
 }
 
-extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepared, const void* bias,
-                                  const int32_t* perm, void* out, int64_t ldo, int64_t M, int64_t K,
-                                  int64_t N, int64_t groups, int act, void* workspace,
-                                  int64_t workspace_bytes, void* stream) {
-    TGIS_CHECK_ARG(x && prepared && out, "tgis_gptq_gemm_f16: null tensor");
-    TGIS_CHECK_ARG(M >= 0 && K > 0 && N > 0 && K % 32 == 0 && N % 32 == 0, "tgis_gptq_gemm_f16: bad shape");
-    TGIS_CHECK_ARG(groups > 0 && K % groups == 0, "tgis_gptq_gemm_f16: K %% groups != 0");
-    TGIS_CHECK_ARG(act == 0 || act == 1, "tgis_gptq_gemm_f16: act must be 0 or 1");
-    TGIS_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, "tgis_gptq_gemm_f16: x must be 16-byte aligned rows");
-    if (M == 0) return TGIS_OK;
-    hipStream_t st = (hipStream_t)stream;
+static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const void* bias, const int32_t* perm,
+                       void* out, int64_t ldo, int64_t M, int64_t K, int64_t N, int64_t groups, int act, float* slabs,
+                       int partial, const GemmPlan& pl, hipStream_t st) {
     PrepLayout p = prep_layout(K, N, groups);
-    GemmPlan pl = plan_gemm(K, N);
     const int64_t mslabs = cdiv64(M, 32);
-    TGIS_CHECK_ARG(mslabs <= 65535, "tgis_gptq_gemm_f16: M too large for one launch");
-    int64_t need = 4096 + slab_bytes(M, N, pl.S);
-    TGIS_CHECK_ARG(workspace && workspace_bytes >= need, "tgis_gptq_gemm_f16: workspace too small (%ld < %ld)",
-                   (long)workspace_bytes, (long)need);
     const int64_t gs = K / groups;
     const bool group64 = (gs % 64 == 0) || groups == 1;
-
-    TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
     GemmArgs a;
     a.x = (const f16*)x;
     a.ldx = ldx;
@@ -491,7 +477,8 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
     a.S = pl.S;
     a.NT = (int)p.NT;
     a.KS = (int)p.KS;
-    a.slabs = (float*)((uint8_t*)workspace + 4096);
+    a.slabs = slabs;
+    a.partial = partial;
     {
         const char* d = getenv("TGIS_GPTQ_DBG");
         a.dbg = d ? atoi(d) : 0;
@@ -521,7 +508,7 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
 #undef TGIS_LAUNCH_GEMM_W
 #undef TGIS_LAUNCH_GEMM
     TGIS_CHECK_LAUNCH();
-    if (pl.S > 1 && !getenv("TGIS_GPTQ_NOREDUCE")) {
+    if (!partial && pl.S > 1 && !getenv("TGIS_GPTQ_NOREDUCE")) {
         const int NP = (int)p.NT * 32;
         dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 4), 256), (unsigned)mslabs);
         hipLaunchKernelGGL(splitk_reduce_f16_kernel, rgrid, dim3(256), 0, st, a.slabs, a.bias, a.out, a.ldo, a.M, a.N,
@@ -529,6 +516,67 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
         TGIS_CHECK_LAUNCH();
     }
     return TGIS_OK;
+}
+
+static int check_gemm_args(const void* x, int64_t ldx, const void* prepared, int64_t M, int64_t K, int64_t N,
+                           int64_t groups, int act) {
+    TGIS_CHECK_ARG(x && prepared, "tgis_gptq_gemm: null tensor");
+    TGIS_CHECK_ARG(M >= 0 && K > 0 && N > 0 && K % 32 == 0 && N % 32 == 0, "tgis_gptq_gemm: bad shape");
+    TGIS_CHECK_ARG(groups > 0 && K % groups == 0, "tgis_gptq_gemm: K %% groups != 0");
+    TGIS_CHECK_ARG(act == 0 || act == 1, "tgis_gptq_gemm: act must be 0 or 1");
+    TGIS_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, "tgis_gptq_gemm: x must be 16-byte aligned rows");
+    return TGIS_OK;
+}
+
+extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepared, const void* bias,
+                                  const int32_t* perm, void* out, int64_t ldo, int64_t M, int64_t K,
+                                  int64_t N, int64_t groups, int act, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    int rc = check_gemm_args(x, ldx, prepared, M, K, N, groups, act);
+    if (rc != TGIS_OK) return rc;
+    TGIS_CHECK_ARG(out, "tgis_gptq_gemm_f16: null out");
+    if (M == 0) return TGIS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    GemmPlan pl = plan_gemm(K, N);
+    TGIS_CHECK_ARG(cdiv64(M, 32) <= 65535, "tgis_gptq_gemm_f16: M too large for one launch");
+    int64_t need = 4096 + slab_bytes(M, N, pl.S);
+    TGIS_CHECK_ARG(workspace && workspace_bytes >= need, "tgis_gptq_gemm_f16: workspace too small (%ld < %ld)",
+                   (long)workspace_bytes, (long)need);
+    TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
+    return launch_gptq(x, ldx, prepared, bias, perm, out, ldo, M, K, N, groups, act,
+                       (float*)((uint8_t*)workspace + 4096), 0, pl, st);
+}
+
+extern "C" int64_t tgis_gptq_gemm_partial_bytes(int64_t K, int64_t N) {
+    GemmPlan pl = plan_gemm(K, N);
+    return (int64_t)pl.S * 32 * cdiv64(N, 32) * 32 * 4;
+}
+
+extern "C" int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void* prepared, const int32_t* perm,
+                                          int64_t M, int64_t K, int64_t N, int64_t groups, int act, float* slabs,
+                                          int64_t slabs_bytes, int* num_slabs, int64_t* slab_ld, void* stream) {
+    int rc = check_gemm_args(x, ldx, prepared, M, K, N, groups, act);
+    if (rc != TGIS_OK) return rc;
+    TGIS_CHECK_ARG(M >= 1 && M <= 32, "tgis_gptq_gemm_f16_partial: M must be in 1..32");
+    GemmPlan pl = plan_gemm(K, N);
+    TGIS_CHECK_ARG(slabs && slabs_bytes >= tgis_gptq_gemm_partial_bytes(K, N),
+                   "tgis_gptq_gemm_f16_partial: slab buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (num_slabs) *num_slabs = pl.S;
+    if (slab_ld) *slab_ld = cdiv64(N, 32) * 32;
+    TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
+    return launch_gptq(x, ldx, prepared, nullptr, perm, nullptr, 0, M, K, N, groups, act, slabs, 1, pl, st);
+}
+
+// debug aid (not part of the documented ABI): resident blocks per CU the runtime reports for the main kernel
+extern "C" int tgis_debug_gemm_occupancy(int wn) {
+    int nb = -1;
+    const size_t lds = 2 * 32 * RS * sizeof(f16);
+    if (wn == 8)
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<8, 0, true, false>, 512, lds);
+    else
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<4, 0, true, false>, 256, lds);
+    return nb;
 }
 
 extern "C" int tgis_gptq_dequant_f16(const void* prepared, void* w_out, int64_t K, int64_t N, int64_t groups,

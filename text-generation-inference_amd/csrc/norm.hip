@@ -20,15 +20,18 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-template <typename T, bool RMS>
+// x either as a model-dtype tensor, or (PARTIAL) as S fp32 split-K slabs [S][32][slab_ld] whose sum (+xbias) is
+// rounded to the model dtype first — bit-identical to running the split-K reduce kernel and then this one.
+template <typename T, bool RMS, bool PARTIAL>
 __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
                                                   const T* __restrict__ weight, const T* __restrict__ bias,
                                                   T* y, T* res_out, int hidden,
-                                                  float eps) {
+                                                  float eps, const float* __restrict__ slabs, int S, int64_t slab_ld,
+                                                  const T* __restrict__ xbias) {
     using V8 = typename VecT<T>::x8;
     __shared__ float sh[4];
     const int64_t row = blockIdx.x;
-    const T* xr = x + row * hidden;
+    const T* xr = PARTIAL ? nullptr : x + row * hidden;
     const T* rr = residual ? residual + row * hidden : nullptr;
     float v[MAXV][8];
     const int nchunk = hidden >> 3;  // hidden % 8 == 0
@@ -37,7 +40,26 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
     for (int it = 0; it < MAXV; ++it) {
         int c = threadIdx.x + it * NT;
         if (c < nchunk) {
-            V8 a = ld16<V8>(xr + c * 8);
+            V8 a;
+            if (PARTIAL) {
+                f32x4 lo, hi;
+                sum_slabs8(slabs + row * slab_ld + c * 8, 32 * slab_ld, S, lo, hi);
+                if (xbias) {
+                    V8 bv = ld16<V8>(xbias + c * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lo[e] += to_f32(bv[e]);
+                        hi[e] += to_f32(bv[e + 4]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = from_f32<T>(lo[e]);
+                    a[e + 4] = from_f32<T>(hi[e]);
+                }
+            } else {
+                a = ld16<V8>(xr + c * 8);
+            }
             V8 o;
             if (rr) {
                 V8 b = ld16<V8>(rr + c * 8);
@@ -99,22 +121,27 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
 
 template <bool RMS>
 static int launch_norm(const void* x, const void* residual, const void* weight, const void* bias, void* y,
-                       void* res_out, int64_t rows, int64_t hidden, float eps, int dtype, void* stream) {
-    TGIS_CHECK_ARG(x && weight && y, "norm: null tensor");
+                       void* res_out, int64_t rows, int64_t hidden, float eps, int dtype, void* stream,
+                       const float* slabs = nullptr, int S = 0, int64_t slab_ld = 0, const void* xbias = nullptr) {
+    TGIS_CHECK_ARG((x || slabs) && weight && y, "norm: null tensor");
+    TGIS_CHECK_ARG(!slabs || (rows <= 32 && S >= 1 && slab_ld >= hidden && slab_ld % 4 == 0),
+                   "norm: partial input needs rows <= 32 and a slab row stride >= hidden");
     TGIS_CHECK_ARG(hidden > 0 && hidden % 8 == 0 && hidden <= NT * 8 * MAXV,
                    "norm: hidden (%ld) must be a multiple of 8 and <= %d", (long)hidden, NT * 8 * MAXV);
     TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "norm: bad dtype");
     if (rows == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
     TgisTimedScope timed(TGIS_OP_NORM, st);
-    if (dtype == TGIS_F16)
-        hipLaunchKernelGGL((norm_kernel<f16, RMS>), dim3((unsigned)rows), dim3(NT), 0, st, (const f16*)x,
-                           (const f16*)residual, (const f16*)weight, (const f16*)bias, (f16*)y, (f16*)res_out,
-                           (int)hidden, eps);
-    else
-        hipLaunchKernelGGL((norm_kernel<bf16, RMS>), dim3((unsigned)rows), dim3(NT), 0, st, (const bf16*)x,
-                           (const bf16*)residual, (const bf16*)weight, (const bf16*)bias, (bf16*)y,
-                           (bf16*)res_out, (int)hidden, eps);
+#define TGIS_NORM_LAUNCH(T, P)                                                                              \
+    hipLaunchKernelGGL((norm_kernel<T, RMS, P>), dim3((unsigned)rows), dim3(NT), 0, st, (const T*)x,             \
+                       (const T*)residual, (const T*)weight, (const T*)bias, (T*)y, (T*)res_out, (int)hidden, eps, \
+                       slabs, S, slab_ld, (const T*)xbias)
+    if (dtype == TGIS_F16) {
+        if (slabs) TGIS_NORM_LAUNCH(f16, true); else TGIS_NORM_LAUNCH(f16, false);
+    } else {
+        if (slabs) TGIS_NORM_LAUNCH(bf16, true); else TGIS_NORM_LAUNCH(bf16, false);
+    }
+#undef TGIS_NORM_LAUNCH
     TGIS_CHECK_LAUNCH();
     return TGIS_OK;
 }
@@ -125,6 +152,14 @@ extern "C" int tgis_rmsnorm_residual(const void* x, const void* residual, const 
                                      void* res_out, int64_t rows, int64_t hidden, float eps, int dtype,
                                      void* stream) {
     return launch_norm<true>(x, residual, weight, nullptr, y, res_out, rows, hidden, eps, dtype, stream);
+}
+
+extern "C" int tgis_rmsnorm_residual_partial(const float* slabs, int num_slabs, int64_t slab_ld, const void* bias,
+                                             const void* residual, const void* weight, void* y, void* res_out,
+                                             int64_t rows, int64_t hidden, float eps, int dtype, void* stream) {
+    TGIS_CHECK_ARG(slabs, "tgis_rmsnorm_residual_partial: null slabs");
+    return launch_norm<true>(nullptr, residual, weight, nullptr, y, res_out, rows, hidden, eps, dtype, stream, slabs,
+                             num_slabs, slab_ld, bias);
 }
 
 extern "C" int tgis_layernorm_residual(const void* x, const void* residual, const void* weight,

@@ -7,6 +7,7 @@
 // KV page block layout for one (page, kv head), 32 tokens x D elements:
 //   K: [tile=tok>>4][D/8][16 tokens][8]      -> MFMA 16x16x32 A-fragments are 1 KiB contiguous loads
 //   V: [D][32], token tok at column (i>>2)*8 + tile*4 + (i&3), i = tok&15 -> V^T A-fragments likewise
+#include <algorithm>
 #include "common.h"
 
 namespace {
@@ -19,12 +20,36 @@ __device__ __forceinline__ int v_col(int tok) {
     return (i >> 2) * 8 + (tok >> 4) * 4 + (i & 3);
 }
 
+template <typename T> struct PartialIn {
+    const float* slabs;  // [S][32][slab_ld] fp32 split-K partial sums of the qkv GEMM, or nullptr
+    int S;
+    int64_t slab_ld;
+    const T* bias;
+};
+
+template <typename T>
+__device__ __forceinline__ typename VecT<T>::x8 load_chunk(const T* hp, int64_t t, int col, const PartialIn<T>& pin) {
+    using V8 = typename VecT<T>::x8;
+    if (pin.slabs == nullptr) return ld16<V8>(hp);
+    f32x4 lo, hi;
+    sum_slabs8(pin.slabs + t * pin.slab_ld + col, 32 * pin.slab_ld, pin.S, lo, hi);
+    V8 a;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float b0 = pin.bias ? to_f32(pin.bias[col + e]) : 0.f, b1 = pin.bias ? to_f32(pin.bias[col + 4 + e]) : 0.f;
+        a[e] = from_f32<T>(lo[e] + b0);
+        a[e + 4] = from_f32<T>(hi[e] + b1);
+    }
+    return a;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void rope_kv_kernel(T* qkv, int64_t ld, const T* __restrict__ cosb,
                                                       const T* __restrict__ sinb,
                                                       const int32_t* __restrict__ positions,
                                                       const int32_t* __restrict__ slots, T* __restrict__ kpool,
-                                                      T* __restrict__ vpool, int H, int Hkv, int D, int rot) {
+                                                      T* __restrict__ vpool, int H, int Hkv, int D, int rot,
+                                                      PartialIn<T> pin) {
     using V8 = typename VecT<T>::x8;
     const int64_t t = blockIdx.x;
     T* row = qkv + t * ld;
@@ -35,16 +60,16 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* qkv, int64_t ld, const 
     const int page = slot >> 5, tok = slot & 31;
     const T* cr = cosb ? cosb + (int64_t)positions[t] * (rot >> 1) : nullptr;
     const T* sr = cosb ? sinb + (int64_t)positions[t] * (rot >> 1) : nullptr;
-    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+    for (int it = blockIdx.y * blockDim.x + threadIdx.x; it < items; it += gridDim.y * blockDim.x) {
         const int head = it / c8, j = it - head * c8;
         T* hp = row + head * D;
         const bool is_v = head >= H + Hkv;
         const bool is_k = head >= H && !is_v;
         const bool roped = cr != nullptr && !is_v;
         if (roped && j >= rh8 && j < 2 * rh8) continue;  // second half: handled with its partner
-        V8 a = ld16<V8>(hp + j * 8);
+        V8 a = load_chunk<T>(hp + j * 8, t, head * D + j * 8, pin);
         if (roped && j < rh8) {
-            V8 b = ld16<V8>(hp + (j + rh8) * 8);
+            V8 b = load_chunk<T>(hp + (j + rh8) * 8, t, head * D + (j + rh8) * 8, pin);
             V8 c = ld16<V8>(cr + j * 8), s = ld16<V8>(sr + j * 8);
             V8 o1, o2;
 #pragma unroll
@@ -60,22 +85,29 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* qkv, int64_t ld, const 
                 st16(kb + k_off(tok, j * 8, D), o1);
                 st16(kb + k_off(tok, (j + rh8) * 8, D), o2);
             }
-        } else if (is_k && kpool) {
-            T* kb = kpool + ((int64_t)page * Hkv + (head - H)) * 32 * D;
-            st16(kb + k_off(tok, j * 8, D), a);
-        } else if (is_v && vpool) {
+        } else if (is_k) {
+            if (pin.slabs) st16(hp + j * 8, a);
+            if (kpool) {
+                T* kb = kpool + ((int64_t)page * Hkv + (head - H)) * 32 * D;
+                st16(kb + k_off(tok, j * 8, D), a);
+            }
+        } else if (is_v) {
+            if (pin.slabs) st16(hp + j * 8, a);
+            if (!vpool) continue;
             T* vb = vpool + ((int64_t)page * Hkv + (head - H - Hkv)) * 32 * D + v_col(tok);
 #pragma unroll
             for (int e = 0; e < 8; ++e) vb[(int64_t)(j * 8 + e) * 32] = a[e];
+        } else if (pin.slabs) {
+            st16(hp + j * 8, a);  // un-rotated q chunk (no rope / beyond the rotary span)
         }
     }
 }
 
 }  // namespace
 
-extern "C" int tgis_rope_kv_write(void* qkv, int64_t ld_qkv, const void* cos, const void* sin,
-                                  const int32_t* positions, const int32_t* slots, void* k_pool, void* v_pool,
-                                  int64_t T, int H, int Hkv, int D, int rot_dim, int dtype, void* stream) {
+static int rope_launch(void* qkv, int64_t ld_qkv, const void* cos, const void* sin, const int32_t* positions,
+                       const int32_t* slots, void* k_pool, void* v_pool, int64_t T, int H, int Hkv, int D, int rot_dim,
+                       int dtype, void* stream, const float* slabs, int S, int64_t slab_ld, const void* bias) {
     TGIS_CHECK_ARG(qkv, "tgis_rope_kv_write: null qkv");
     TGIS_CHECK_ARG(H > 0 && Hkv >= 0 && D > 0 && D % 16 == 0, "tgis_rope_kv_write: head_dim must be a multiple of 16");
     TGIS_CHECK_ARG(ld_qkv % 8 == 0 && ld_qkv >= (int64_t)(H + 2 * Hkv) * D, "tgis_rope_kv_write: bad row stride");
@@ -84,17 +116,42 @@ extern "C" int tgis_rope_kv_write(void* qkv, int64_t ld_qkv, const void* cos, co
                    "tgis_rope_kv_write: rot_dim must be a multiple of 16 and <= head_dim");
     TGIS_CHECK_ARG((!k_pool && !v_pool) || slots, "tgis_rope_kv_write: cache write needs slots");
     TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "tgis_rope_kv_write: bad dtype");
+    TGIS_CHECK_ARG(!slabs || (T <= 32 && S >= 1 && slab_ld >= (int64_t)(H + 2 * Hkv) * D && slab_ld % 4 == 0),
+                   "tgis_rope_kv_write_partial: needs T <= 32 and a slab row stride >= (H + 2 Hkv) D");
     if (T == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
     TgisTimedScope timed(TGIS_OP_ROPE_KV, st);
-    if (dtype == TGIS_F16)
-        hipLaunchKernelGGL(rope_kv_kernel<f16>, dim3((unsigned)T), dim3(256), 0, st, (f16*)qkv, ld_qkv,
+    // decode-sized T: spread one token's (H + 2 Hkv) * D/8 work items over several workgroups
+    const int items = (H + 2 * Hkv) * (D >> 3);
+    const unsigned gy = T <= 64 ? (unsigned)std::min(16, (items + 255) / 256) : 1u;
+    const dim3 grid((unsigned)T, gy);
+    if (dtype == TGIS_F16) {
+        PartialIn<f16> pin{slabs, S, slab_ld, (const f16*)bias};
+        hipLaunchKernelGGL(rope_kv_kernel<f16>, grid, dim3(256), 0, st, (f16*)qkv, ld_qkv,
                            (const f16*)cos, (const f16*)sin, positions, slots, (f16*)k_pool, (f16*)v_pool, H, Hkv,
-                           D, rot_dim);
-    else
-        hipLaunchKernelGGL(rope_kv_kernel<bf16>, dim3((unsigned)T), dim3(256), 0, st, (bf16*)qkv, ld_qkv,
+                           D, rot_dim, pin);
+    } else {
+        PartialIn<bf16> pin{slabs, S, slab_ld, (const bf16*)bias};
+        hipLaunchKernelGGL(rope_kv_kernel<bf16>, grid, dim3(256), 0, st, (bf16*)qkv, ld_qkv,
                            (const bf16*)cos, (const bf16*)sin, positions, slots, (bf16*)k_pool, (bf16*)v_pool, H,
-                           Hkv, D, rot_dim);
+                           Hkv, D, rot_dim, pin);
+    }
     TGIS_CHECK_LAUNCH();
     return TGIS_OK;
+}
+
+extern "C" int tgis_rope_kv_write(void* qkv, int64_t ld_qkv, const void* cos, const void* sin,
+                                  const int32_t* positions, const int32_t* slots, void* k_pool, void* v_pool,
+                                  int64_t T, int H, int Hkv, int D, int rot_dim, int dtype, void* stream) {
+    return rope_launch(qkv, ld_qkv, cos, sin, positions, slots, k_pool, v_pool, T, H, Hkv, D, rot_dim, dtype, stream,
+                       nullptr, 0, 0, nullptr);
+}
+
+extern "C" int tgis_rope_kv_write_partial(const float* slabs, int num_slabs, int64_t slab_ld, const void* bias,
+                                          void* qkv_out, int64_t ld_qkv, const void* cos, const void* sin,
+                                          const int32_t* positions, const int32_t* slots, void* k_pool, void* v_pool,
+                                          int64_t T, int H, int Hkv, int D, int rot_dim, int dtype, void* stream) {
+    TGIS_CHECK_ARG(slabs, "tgis_rope_kv_write_partial: null slabs");
+    return rope_launch(qkv_out, ld_qkv, cos, sin, positions, slots, k_pool, v_pool, T, H, Hkv, D, rot_dim, dtype,
+                       stream, slabs, num_slabs, slab_ld, bias);
 }

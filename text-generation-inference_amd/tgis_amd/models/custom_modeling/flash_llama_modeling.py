@@ -113,10 +113,11 @@ class FlashLlamaAttention:
 
     def forward(self, hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id: int, kv: KVArgs):
         H, Hkv, D = self.num_heads, self.num_key_value_heads, self.head_size
-        qkv = self.query_key_value(hidden_states)  # [T, (H + 2 Hkv) D]
+        # [T, (H + 2 Hkv) D]; at decode sizes the split-K sum of the GPTQ GEMM is finished inside the rope kernel
+        qkv = self.query_key_value(hidden_states, partial=True)
         k_pool, v_pool = kv.cache.k_pool(layer_id), kv.cache.v_pool(layer_id)
         # rotate q,k in place and scatter k,v to their page slots (reference :252-268,282)
-        native.rope_kv_write(qkv, cos, sin, position_ids, kv.slots, k_pool, v_pool, H, Hkv, D, D)
+        qkv = native.rope_kv_write(qkv, cos, sin, position_ids, kv.slots, k_pool, v_pool, H, Hkv, D, D)
         T = qkv.shape[0]
         attn_output = torch.empty((T, H * D), dtype=qkv.dtype, device=qkv.device)
         B = kv.block_tables.shape[0]
@@ -127,7 +128,8 @@ class FlashLlamaAttention:
             ws.ensure(native.attn_workspace_bytes(T, H, D, kv.num_splits))
         native.attn_paged(qkv, qkv.stride(0), k_pool, v_pool, kv.block_tables, kv.ctx_lens, cu_seqlens_q,
                           attn_output, B, H, Hkv, D, kv.max_q_len, kv.max_ctx, self.softmax_scale, kv.num_splits, ws)
-        return self.o_proj(attn_output)
+        # may be a native.Partial: the following fused add+RMSNorm finishes the split-K sum
+        return self.o_proj(attn_output, partial=True)
 
     __call__ = forward
 
@@ -146,7 +148,7 @@ class LlamaMLP:
     def forward(self, hidden_states):
         gate_up_states = self.gate_up_proj(hidden_states)  # [T, 2, I]
         # act(gate) * up is applied while down_proj stages its operand (reference :332-335)
-        return self.down_proj(gate_up_states, act=1)
+        return self.down_proj(gate_up_states, act=1, partial=True)
 
     __call__ = forward
 

@@ -39,6 +39,9 @@ SIGNATURES = {
     "tgis_gptq_gemm_workspace_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
     "tgis_gptq_gemm_f16": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64,
                                     _c_int, _vp, _c_i64, _vp]),
+    "tgis_gptq_gemm_partial_bytes": (_c_i64, [_c_i64, _c_i64]),
+    "tgis_gptq_gemm_f16_partial": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_i64,
+                                            ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64), _vp]),
     "tgis_gptq_dequant_f16": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_i64, _vp]),
     "tgis_dense_prepared_bytes": (_c_i64, [_c_i64, _c_i64]),
     "tgis_dense_prepare": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _vp, _vp]),
@@ -46,9 +49,13 @@ SIGNATURES = {
     "tgis_dense_gemm": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int,
                                  _c_int, _vp, _c_i64, _vp]),
     "tgis_rmsnorm_residual": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f, _c_int, _vp]),
+    "tgis_rmsnorm_residual_partial": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f,
+                                               _c_int, _vp]),
     "tgis_layernorm_residual": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f, _c_int, _vp]),
     "tgis_rope_kv_write": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_int, _c_int, _c_int,
                                     _c_int, _c_int, _vp]),
+    "tgis_rope_kv_write_partial": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64,
+                                            _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "tgis_attn_num_splits": (_c_int, [_c_i64, _c_int, _c_int, _c_i64, _c_i64]),
     "tgis_attn_workspace_bytes": (_c_i64, [_c_i64, _c_int, _c_int, _c_int]),
     "tgis_attn_paged": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_int, _c_int,
@@ -212,6 +219,35 @@ def gptq_gemm(x: torch.Tensor, w: GptqWeight, ws: Workspace, bias=None, act: int
     return out
 
 
+class Partial:
+    """fp32 split-K partial sums [S, 32, ld] of a GEMM whose reduce is deferred to the consumer kernel
+    (rmsnorm_residual / rope_kv_write accept it in place of the f16 activation)."""
+
+    def __init__(self, slabs: torch.Tensor, S: int, ld: int, M: int, N: int, bias):
+        self.slabs, self.S, self.ld, self.M, self.N, self.bias = slabs, S, ld, M, N, bias
+        self.dtype = torch.float16
+        self.device = slabs.device
+
+    @property
+    def shape(self):
+        return (self.M, self.N)
+
+
+def gptq_gemm_partial(x: torch.Tensor, w: GptqWeight, bias=None, act: int = 0) -> Partial:
+    """Launch the GEMM but leave the split-K reduce (and bias) to the consumer.  M <= 32."""
+    assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] <= 32
+    lib = load_library()
+    nbytes = lib.tgis_gptq_gemm_partial_bytes(w.K, w.N)
+    slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    S = _c_int()
+    ld = _c_i64()
+    _check(
+        lib.tgis_gptq_gemm_f16_partial(_ptr(x), x.stride(0), _ptr(w.image), _ptr(w.perm), x.shape[0], w.K, w.N,
+                                       w.groups, act, _ptr(slabs), nbytes, ctypes.byref(S), ctypes.byref(ld),
+                                       _stream()), "tgis_gptq_gemm_f16_partial")
+    return Partial(slabs, S.value, ld.value, x.shape[0], w.N, bias)
+
+
 def gptq_dequant(w: GptqWeight) -> torch.Tensor:
     """Dense f16 [K,N] (rows in the prepared order: permuted by w.perm for act-order matrices)."""
     out = torch.empty((w.K, w.N), dtype=torch.float16, device=w.image.device)
@@ -258,6 +294,18 @@ def dense_gemm(x: torch.Tensor, w: DenseWeight, ws: Workspace, bias=None, out_f3
 # ---- norms --------------------------------------------------------------------------------------------
 def rmsnorm_residual(x, residual, weight, eps: float, y=None, res_out=None):
     """(y, res) = fused add + RMSNorm; mirrors LlamaRMSNorm.forward (flash_llama_modeling.py:113-152)."""
+    if isinstance(x, Partial):
+        rows, hidden = x.shape
+        if y is None:
+            y = torch.empty((rows, hidden), dtype=x.dtype, device=x.device)
+        if res_out is None:
+            res_out = torch.empty_like(y)  # always materialised: it is the reduced (+residual) stream
+        _check(
+            load_library().tgis_rmsnorm_residual_partial(_ptr(x.slabs), x.S, x.ld, _ptr(x.bias), _ptr(residual),
+                                                         _ptr(weight), _ptr(y), _ptr(res_out), rows, hidden,
+                                                         float(eps), dtype_code(x.dtype), _stream()),
+            "tgis_rmsnorm_residual_partial")
+        return y, res_out
     assert x.dim() == 2 and x.is_contiguous()
     rows, hidden = x.shape
     if y is None:
@@ -289,12 +337,24 @@ def layernorm_residual(x, residual, weight, bias, eps: float, y=None, res_out=No
 
 # ---- rope + kv write, attention --------------------------------------------------------------------------
 def rope_kv_write(qkv, cos, sin, positions, slots, k_pool, v_pool, H: int, Hkv: int, D: int, rot_dim: int):
+    """Rotates q,k in place and writes k,v to the cache.  `qkv` may be a Partial: the reduced, rotated activation is
+    then materialised into a fresh [T, (H+2Hkv)D] tensor, which is returned (the plain form returns qkv itself)."""
+    if isinstance(qkv, Partial):
+        T = qkv.M
+        out = torch.empty((T, qkv.N), dtype=qkv.dtype, device=qkv.device)
+        _check(
+            load_library().tgis_rope_kv_write_partial(_ptr(qkv.slabs), qkv.S, qkv.ld, _ptr(qkv.bias), _ptr(out),
+                                                      out.stride(0), _ptr(cos), _ptr(sin), _ptr(positions),
+                                                      _ptr(slots), _ptr(k_pool), _ptr(v_pool), T, H, Hkv, D, rot_dim,
+                                                      dtype_code(out.dtype), _stream()), "tgis_rope_kv_write_partial")
+        return out
     assert qkv.dim() == 2 and qkv.stride(1) == 1
     T = qkv.shape[0]
     _check(
         load_library().tgis_rope_kv_write(_ptr(qkv), qkv.stride(0), _ptr(cos), _ptr(sin), _ptr(positions),
                                           _ptr(slots), _ptr(k_pool), _ptr(v_pool), T, H, Hkv, D, rot_dim,
                                           dtype_code(qkv.dtype), _stream()), "tgis_rope_kv_write")
+    return qkv
 
 
 def attn_num_splits(B: int, Hkv: int, H: int, max_q_len: int, max_ctx: int) -> int:

@@ -24,7 +24,10 @@ class PagedKVCache:
         self.num_pages = num_pages
         # zero-initialised: masked slots are multiplied by P = 0, so they must never hold NaN/Inf patterns
         self.pool = torch.zeros((num_layers, 2, num_pages, num_kv_heads, PAGE * head_dim), dtype=dtype, device=device)
-        self._free = list(range(num_pages - 1, -1, -1))
+        # hand pages out in a fixed pseudo-random order: a sequence's consecutive pages would otherwise sit at a
+        # constant Hkv*page stride, and equal-phase waves of the decode kernel would camp on the same HBM channels
+        order = torch.randperm(num_pages, generator=torch.Generator().manual_seed(0x5eed)).tolist()
+        self._free = order
 
     @property
     def free_pages(self) -> int:

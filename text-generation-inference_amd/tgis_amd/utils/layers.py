@@ -15,8 +15,12 @@ from torch.nn import functional as F
 
 from tgis_amd import native
 
+import os
+
 # rows up to which the weight-streaming MFMA kernels are used; above, dequant/hipBLASLt GEMM
 SKINNY_MAX_M = 64
+# fuse the split-K reduce of decode-sized GPTQ GEMMs into the consumer kernel (rmsnorm / rope+KV write)
+DEFER_REDUCE = os.getenv("TGIS_DEFER_REDUCE", "true").lower() not in ("0", "false")
 
 _WORKSPACES = {}
 
@@ -36,7 +40,7 @@ class FastLinear:
         self.prepared = native.DenseWeight(weight)
         self.out_features, self.in_features = weight.shape
 
-    def forward(self, x: torch.Tensor, act: int = 0, out_f32: bool = False) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, act: int = 0, out_f32: bool = False, partial: bool = False) -> torch.Tensor:
         if x.shape[0] <= SKINNY_MAX_M:
             return native.dense_gemm(x, self.prepared, workspace(x.device), bias=self.bias, out_f32=out_f32, act=act)
         if act:
@@ -79,9 +83,12 @@ class Ex4bitLinearV2:
                                                              device=self.device)
         return buf
 
-    def forward(self, x: torch.Tensor, act: int = 0) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, act: int = 0, partial: bool = False):
+        """partial=True (decode-sized M only): return native.Partial — the consumer kernel finishes the split-K sum."""
         if self.q_handle is None:
             self.post_init()
+        if partial and x.shape[0] <= 32 and DEFER_REDUCE:
+            return native.gptq_gemm_partial(x, self.q_handle, bias=self.bias, act=act)
         if x.shape[0] <= SKINNY_MAX_M:
             return native.gptq_gemm(x, self.q_handle, workspace(x.device), bias=self.bias, act=act)
         # prefill-sized M: dequantise once into scratch, then a library GEMM (exllamav2.py:87 "M > 50")
@@ -192,10 +199,12 @@ class TensorParallelRowLinear(SuperLayer):
         return cls(get_linear(weight, bias, config.quantize), process_group=weights.process_group)
 
     def forward(self, x: torch.Tensor, **kw) -> torch.Tensor:
-        out = self.linear.forward(x, **kw)
         if self.process_group.size() > 1:
+            kw.pop("partial", None)  # the all-reduce needs the reduced f16 tensor
+            out = self.linear.forward(x, **kw)
             torch.distributed.all_reduce(out, group=self.process_group)
-        return out
+            return out
+        return self.linear.forward(x, **kw)
 
     __call__ = forward
 
