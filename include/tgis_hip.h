@@ -72,10 +72,13 @@ int64_t tgis_gptq_prepared_bytes(int64_t K, int64_t N, int64_t groups);
  *   when g_idx is not the trivial map (act-order) perm_out receives the row permutation that the
  *   activation must be gathered with (x'[:,k'] = x[:,perm[k']]); groupsize = K / groups.
  *   prepared: caller-owned buffer of tgis_gptq_prepared_bytes().  Requires K%32==0, N%32==0
- *   (same asserts as exllamav2.py:118-119) and (K/groups)%16==0. */
+ *   (same asserts as exllamav2.py:118-119) and (K/groups)%8==0.
+ *   flags bit 0 (TGIS_GPTQ_GATE_UP): the matrix is a fused [gate | up] projection (N = 2 I); columns are
+ *   interleaved in the image so that tgis_gptq_gemm_f16(act=2) can apply SiLU(gate)*up in its epilogue. */
+#define TGIS_GPTQ_GATE_UP 1
 int tgis_gptq_prepare(const int32_t* qweight, const int32_t* qzeros, const void* scales,
                       const int32_t* g_idx_host, int32_t* perm_out, int64_t K, int64_t N,
-                      int64_t groups, void* prepared, void* stream);
+                      int64_t groups, int flags, void* prepared, void* stream);
 
 /* Workspace for split-K partial sums + arrival counters of one gemm call. The counter region
  * (first 4096 bytes) must be zero before the first call; the kernel leaves it zero. */
@@ -84,8 +87,9 @@ int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
 /* out[M,N] f16 = x[M,K] f16 @ dequant(W)[K,N] (+ bias[N] f16 if non-NULL); fp32 accumulate.
  * Fused int4-dequant MFMA kernel for any M (rows are processed in slabs of 32).
  * x row stride ldx, out row stride ldo (elements).  perm (int32 [K] or NULL) gathers x columns
- * for act-order matrices.  act: 0 = none, 1 = x is [M,2K] and the kernel consumes
- * silu(x[:, :K]) * x[:, K:]  (fuses LlamaMLP's activation, flash_llama_modeling.py:332-335). */
+ * for act-order matrices.  act: 0 = none; 1 = x is [M,2K] and the kernel consumes silu(x[:, :K]) * x[:, K:]
+ * while staging it; 2 = the image was prepared with TGIS_GPTQ_GATE_UP and out is [M, N/2] =
+ * silu(gate) * up applied in the epilogue (both fuse LlamaMLP's activation, flash_llama_modeling.py:332-335). */
 int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepared, const void* bias,
                        const int32_t* perm, void* out, int64_t ldo, int64_t M, int64_t K, int64_t N,
                        int64_t groups, int act, void* workspace, int64_t workspace_bytes, void* stream);
@@ -103,7 +107,7 @@ int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void* prepared,
 /* Full dequantisation to a dense f16 [K,N] matrix (row-major), the "temp_dq" path the reference
  * uses for M > 50 before a library GEMM (exllamav2.py:65-66,87). */
 int tgis_gptq_dequant_f16(const void* prepared, void* w_out, int64_t K, int64_t N, int64_t groups,
-                          void* stream);
+                          int flags, void* stream);
 
 /* ---- dense skinny GEMM (replaces F.linear / torch.mm at decode sizes, utils/layers.py:110-111,
  *      lm_head utils/layers.py:261) -------------------------------------------------------------- */

@@ -18,7 +18,8 @@ class _Workspace:
 
 
 class _GptqWeight:
-    def __init__(self, qweight, qzeros, scales, g_idx, bits, groupsize):
+    def __init__(self, qweight, qzeros, scales, g_idx, bits, groupsize, gate_up=False):
+        self.flags = 1 if gate_up else 0
         self.K, self.N = qweight.shape[0] * 8, qweight.shape[1]
         self.groups = qzeros.shape[0]
         self.perm = None
@@ -45,11 +46,14 @@ def _act(x, K):
 
 
 def _gptq_gemm(x, w, ws, bias=None, act=0, out=None):
-    xf = _act(x, w.K) if act else x.float()
+    xf = _act(x, w.K) if act == 1 else x.float()
     y = xf @ w.w
     if bias is not None:
         y = y + bias.float()
-    return y.to(torch.float16)
+    y = y.to(torch.float16)
+    if act == 2:
+        y = ops_ref.silu_mul(y, w.N // 2).to(torch.float16)
+    return y
 
 
 def _dense_gemm(x, w, ws, bias=None, out_f32=False, act=0, out=None):

@@ -332,3 +332,27 @@ def test_gptq_partial_then_rope_kv_is_bit_identical_to_unfused(nat, gpu_device):
     q1 = nat.rope_kv_write(part, cos, sin, pos, slots, pools[2], pools[3], H, Hkv, D, D)
     assert torch.equal(q0, q1) and torch.equal(pools[0], pools[2]) and torch.equal(pools[1], pools[3])
     assert pools[0].abs().sum() > 0
+
+
+@pytest.mark.parametrize("M,K,I", [(32, 4096, 11008), (3, 256, 48), (40, 512, 1376)])
+def test_gptq_gemm_gate_up_epilogue(nat, gpu_device, M, K, I):
+    """act=2: fused [gate | up] projection with SiLU(gate)*up in the epilogue (columns interleaved at prepare time),
+    and the dequant path must still return the matrix in checkpoint column order."""
+    gs = 128 if K % 128 == 0 else 64
+    N = 2 * I
+    qw, qz, sc, gi = ops_ref.make_gptq_tensors(K, N, gs, seed=K + I)
+    g = torch.Generator().manual_seed(M + 1)
+    x = (torch.randn(M, K, generator=g) * 0.5).half()
+    bias = (torch.randn(N, generator=g) * 0.05).half()
+    w = nat.GptqWeight(torch.from_numpy(qw).to(gpu_device), torch.from_numpy(qz).to(gpu_device),
+                       torch.from_numpy(sc).to(gpu_device), None, 4, gs, gate_up=True)
+    ws = nat.Workspace(w.workspace_bytes(M), gpu_device)
+    got = nat.gptq_gemm(x.to(gpu_device), w, ws, bias=bias.to(gpu_device), act=2)
+    assert got.shape == (M, I)
+    lin = ops_ref.gptq_linear(x, qw, qz, sc, gi, gs, bias).half()
+    want = torch.nn.functional.silu(lin[:, :I].float()).half().float() * lin[:, I:].float()
+    # gate and up are each rounded to f16 (rel 2^-11 of |lin|) before silu(gate)*up: the absolute error of the
+    # product scales with max|lin| (error in gate times |up|), not with the size of the (possibly tiny) product
+    _close(got, want, rtol=4e-3, atol=1.5e-3 * float(lin.float().abs().max()) + 1e-4, what="gate_up epilogue")
+    wd = nat.gptq_dequant(w).float().cpu()
+    assert torch.equal(wd, ops_ref.gptq_dequant(qw, qz, sc, gi, gs).half().float())

@@ -35,12 +35,20 @@ static PrepLayout prep_layout(int64_t K, int64_t N, int64_t G) {
     return p;
 }
 
+// Column held by lane c (0..31) of tile nt.  flags bit 0 (gate/up interleave, for the fused SiLU*mul epilogue):
+// lanes 0-15 hold gate columns 16 nt + c, lanes 16-31 the matching up columns N/2 + 16 nt + (c - 16).
+__device__ __forceinline__ int64_t col_src(int64_t nt, int c, int64_t N, int flags) {
+    if (flags & 1) return (c < 16) ? nt * 16 + c : (N >> 1) + nt * 16 + (c - 16);
+    return nt * 32 + c;
+}
+
 __device__ __forceinline__ int nib_src(int j) {  // stored nibble j holds row offset {0,2,4,6,1,3,5,7}[j]
     return (j < 4) ? 2 * j : 2 * (j - 4) + 1;
 }
 
 __global__ void gptq_prepare_w_kernel(const int32_t* __restrict__ qweight, const int32_t* __restrict__ perm,
-                                      int32_t* __restrict__ wq, int64_t K, int64_t N, int64_t NT, int64_t KS) {
+                                      int32_t* __restrict__ wq, int64_t K, int64_t N, int64_t NT, int64_t KS,
+                                      int flags) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = NT * KS * 256;
     if (idx >= total) return;
@@ -48,7 +56,7 @@ __global__ void gptq_prepare_w_kernel(const int32_t* __restrict__ qweight, const
     int l = (idx >> 2) & 63;
     int64_t ks = (idx >> 8) % KS;
     int64_t nt = (idx >> 8) / KS;
-    int64_t n = nt * 32 + (l & 31);
+    int64_t n = col_src(nt, l & 31, N, flags);
     int64_t p = ks * 8 + (l >> 5) * 4 + i;  // k-pack row (8 k each)
     uint32_t v = 0;
     if (n < N && p * 8 < K) {
@@ -69,13 +77,13 @@ __global__ void gptq_prepare_w_kernel(const int32_t* __restrict__ qweight, const
 }
 
 __global__ void gptq_prepare_sz_kernel(const int32_t* __restrict__ qzeros, const f16* __restrict__ scales,
-                                       uint32_t* __restrict__ sz, int64_t N, int64_t NT, int64_t G) {
+                                       uint32_t* __restrict__ sz, int64_t N, int64_t NT, int64_t G, int flags) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= NT * G * 32) return;
     int c = idx & 31;
     int64_t g = (idx >> 5) % G;
     int64_t nt = (idx >> 5) / G;
-    int64_t n = nt * 32 + c;
+    int64_t n = col_src(nt, c, N, flags);
     f16x2 v = {(f16)0.f, (f16)1025.f};
     if (n < N) {
         uint32_t w = (uint32_t)qzeros[g * (N / 8) + (n >> 3)];
@@ -296,6 +304,27 @@ __global__ __launch_bounds__(64 * WN) void gptq_gemm_kernel(GemmArgs a) {
     if (nt_raw >= a.NT) return;
     const f32x16 acc = (accs[0] + accs[1]) + (accs[2] + accs[3]);
     const int n = nt * 32 + (lane & 31);
+    if (ACT == 2) {
+        // columns are interleaved gate/up pairs (col_src flags bit 0): lanes c < 16 hold gate column j = 16 nt + c,
+        // lanes c + 16 the matching up column.  out[m][j] = f16(f16(silu(f16 gate)) * f16 up), the rounding
+        // sequence of the reference's eager ops (flash_llama_modeling.py:332-335).  Host guarantees S == 1.
+        const int c = lane & 31;
+        const int half = a.N >> 1;
+        const int j = nt * 16 + (c & 15);
+        const int nsrc = (c < 16) ? j : half + j;
+        const float bv = (a.bias && j < half) ? (float)a.bias[nsrc] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float mine = (float)(f16)(acc[r] + bv);
+            const float other = __shfl_xor(mine, 16, 64);
+            int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (c < 16 && j < half && m < mrows) {
+                float sl = mine / (1.f + __expf(-mine));
+                a.out[(int64_t)(m0 + m) * a.ldo + j] = (f16)((float)(f16)sl * other);
+            }
+        }
+        return;
+    }
     if (a.S == 1 && !a.partial) {
         const float bv = (a.bias && n < a.N) ? (float)a.bias[n] : 0.f;
         if (n < a.N) {
@@ -340,7 +369,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16_kernel(const float* __r
 }
 
 __global__ void gptq_dequant_kernel(const uint8_t* __restrict__ prep, int64_t offB, f16* __restrict__ wout,
-                                    int K, int N, int G, int gs, int NT, int KS) {
+                                    int K, int N, int G, int gs, int NT, int KS, int flags) {
     // one thread per prepared int32 (8 k of one column)
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)NT * KS * 256) return;
@@ -348,7 +377,7 @@ __global__ void gptq_dequant_kernel(const uint8_t* __restrict__ prep, int64_t of
     int l = (idx >> 2) & 63;
     int64_t ks = (idx >> 8) % KS;
     int64_t nt = (idx >> 8) / KS;
-    int n = nt * 32 + (l & 31);
+    int n = (int)col_src(nt, l & 31, N, flags);
     int k0 = (ks * 8 + (l >> 5) * 4 + i) * 8;
     if (n >= N || k0 >= K) return;
     uint32_t q = reinterpret_cast<const uint32_t*>(prep)[idx];
@@ -388,7 +417,7 @@ static GemmPlan plan_gemm(int64_t K, int64_t N) {
         int64_t KRc = cdiv64(kchunks, S);
         if ((S - 1) * KRc >= kchunks) continue;  // empty last split
         best = {(int)(KRc * KC), (int)S, WN};
-        if (tiles * S >= 680 || KRc <= 2) break;
+        if (tiles * S >= (kchunks > 16 ? 1000 : 680) || KRc <= 2) break;
     }
     return best;
 }
@@ -406,8 +435,9 @@ extern "C" int64_t tgis_gptq_prepared_bytes(int64_t K, int64_t N, int64_t groups
 
 extern "C" int tgis_gptq_prepare(const int32_t* qweight, const int32_t* qzeros, const void* scales,
                                  const int32_t* g_idx_host, int32_t* perm_out, int64_t K, int64_t N,
-                                 int64_t groups, void* prepared, void* stream) {
+                                 int64_t groups, int flags, void* prepared, void* stream) {
     TGIS_CHECK_ARG(qweight && qzeros && scales && prepared, "tgis_gptq_prepare: null tensor");
+    TGIS_CHECK_ARG(!(flags & 1) || (N % 32 == 0), "tgis_gptq_prepare: gate/up interleave needs N/2 %% 16 == 0");
     TGIS_CHECK_ARG(K > 0 && N > 0 && K % 32 == 0 && N % 32 == 0,
                    "tgis_gptq_prepare: K (%ld) and N (%ld) must be positive multiples of 32", (long)K, (long)N);
     TGIS_CHECK_ARG(groups > 0 && K % groups == 0, "tgis_gptq_prepare: K %% groups != 0");
@@ -438,11 +468,11 @@ extern "C" int tgis_gptq_prepare(const int32_t* qweight, const int32_t* qzeros, 
     uint8_t* base = (uint8_t*)prepared;
     int64_t totalA = p.NT * p.KS * 256;
     hipLaunchKernelGGL(gptq_prepare_w_kernel, dim3((unsigned)cdiv64(totalA, 256)), dim3(256), 0, st, qweight,
-                       perm_dev, (int32_t*)base, K, N, p.NT, p.KS);
+                       perm_dev, (int32_t*)base, K, N, p.NT, p.KS, flags);
     TGIS_CHECK_LAUNCH();
     int64_t totalB = p.NT * groups * 32;
     hipLaunchKernelGGL(gptq_prepare_sz_kernel, dim3((unsigned)cdiv64(totalB, 256)), dim3(256), 0, st, qzeros,
-                       (const f16*)scales, (uint32_t*)(base + p.offB), N, p.NT, groups);
+                       (const f16*)scales, (uint32_t*)(base + p.offB), N, p.NT, groups, flags);
     TGIS_CHECK_LAUNCH();
     return TGIS_OK;
 }
@@ -494,8 +524,12 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
         else                                    \
             TGIS_LAUNCH_GEMM(4, A, G, P);       \
     } while (0)
-    const int variant = (act ? 4 : 0) | (group64 ? 2 : 0) | (perm ? 1 : 0);
+    const int variant = (act == 1 ? 4 : act == 2 ? 8 : 0) | (group64 ? 2 : 0) | (perm ? 1 : 0);
     switch (variant) {
+        case 8: TGIS_LAUNCH_GEMM_W(2, false, false); break;
+        case 9: TGIS_LAUNCH_GEMM_W(2, false, true); break;
+        case 10: TGIS_LAUNCH_GEMM_W(2, true, false); break;
+        case 11: TGIS_LAUNCH_GEMM_W(2, true, true); break;
         case 0: TGIS_LAUNCH_GEMM_W(0, false, false); break;
         case 1: TGIS_LAUNCH_GEMM_W(0, false, true); break;
         case 2: TGIS_LAUNCH_GEMM_W(0, true, false); break;
@@ -523,7 +557,8 @@ static int check_gemm_args(const void* x, int64_t ldx, const void* prepared, int
     TGIS_CHECK_ARG(x && prepared, "tgis_gptq_gemm: null tensor");
     TGIS_CHECK_ARG(M >= 0 && K > 0 && N > 0 && K % 32 == 0 && N % 32 == 0, "tgis_gptq_gemm: bad shape");
     TGIS_CHECK_ARG(groups > 0 && K % groups == 0, "tgis_gptq_gemm: K %% groups != 0");
-    TGIS_CHECK_ARG(act == 0 || act == 1, "tgis_gptq_gemm: act must be 0 or 1");
+    TGIS_CHECK_ARG(act == 0 || act == 1 || act == 2, "tgis_gptq_gemm: act must be 0, 1 or 2");
+    TGIS_CHECK_ARG(act != 2 || N % 32 == 0, "tgis_gptq_gemm: act=2 needs N/2 to be a multiple of 16");
     TGIS_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, "tgis_gptq_gemm: x must be 16-byte aligned rows");
     return TGIS_OK;
 }
@@ -538,6 +573,7 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
     if (M == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
     GemmPlan pl = plan_gemm(K, N);
+    if (act == 2) pl = {(int)(cdiv64(K, KC) * KC), 1, pl.WN};  // the nonlinearity needs the complete sum
     TGIS_CHECK_ARG(cdiv64(M, 32) <= 65535, "tgis_gptq_gemm_f16: M too large for one launch");
     int64_t need = 4096 + slab_bytes(M, N, pl.S);
     TGIS_CHECK_ARG(workspace && workspace_bytes >= need, "tgis_gptq_gemm_f16: workspace too small (%ld < %ld)",
@@ -558,6 +594,7 @@ extern "C" int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void
     int rc = check_gemm_args(x, ldx, prepared, M, K, N, groups, act);
     if (rc != TGIS_OK) return rc;
     TGIS_CHECK_ARG(M >= 1 && M <= 32, "tgis_gptq_gemm_f16_partial: M must be in 1..32");
+    TGIS_CHECK_ARG(act != 2, "tgis_gptq_gemm_f16_partial: act=2 cannot be deferred");
     GemmPlan pl = plan_gemm(K, N);
     TGIS_CHECK_ARG(slabs && slabs_bytes >= tgis_gptq_gemm_partial_bytes(K, N),
                    "tgis_gptq_gemm_f16_partial: slab buffer too small");
@@ -580,14 +617,14 @@ extern "C" int tgis_debug_gemm_occupancy(int wn) {
 }
 
 extern "C" int tgis_gptq_dequant_f16(const void* prepared, void* w_out, int64_t K, int64_t N, int64_t groups,
-                                     void* stream) {
+                                     int flags, void* stream) {
     TGIS_CHECK_ARG(prepared && w_out && K > 0 && N > 0 && groups > 0 && K % groups == 0,
                    "tgis_gptq_dequant_f16: bad arguments");
     PrepLayout p = prep_layout(K, N, groups);
     int64_t total = p.NT * p.KS * 256;
     hipLaunchKernelGGL(gptq_dequant_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t*)prepared, p.offB, (f16*)w_out, (int)K, (int)N, (int)groups,
-                       (int)(K / groups), (int)p.NT, (int)p.KS);
+                       (int)(K / groups), (int)p.NT, (int)p.KS, flags);
     TGIS_CHECK_LAUNCH();
     return TGIS_OK;
 }

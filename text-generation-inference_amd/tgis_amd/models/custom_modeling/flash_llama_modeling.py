@@ -144,10 +144,17 @@ class LlamaMLP:
         self.down_proj = TensorParallelRowLinear.load(config, prefix=f"{prefix}.down_proj", weights=weights,
                                                       bias=config.mlp_bias)
         self.intermediate_size = config.intermediate_size // weights.process_group.size()
+        # GPTQ: SiLU(gate)*up runs in the gate_up GEMM epilogue (columns interleaved at prepare time);
+        # dense: it runs while down_proj stages its operand.  Reference: eager ops at :332-335.
+        self.fused_epilogue = hasattr(self.gate_up_proj.linear, "gate_up") and self.intermediate_size % 16 == 0
+        if self.fused_epilogue:
+            self.gate_up_proj.linear.gate_up = True
 
     def forward(self, hidden_states):
+        if self.fused_epilogue:
+            act = self.gate_up_proj(hidden_states)  # [T, I], already silu(gate) * up
+            return self.down_proj(act, partial=True)
         gate_up_states = self.gate_up_proj(hidden_states)  # [T, 2, I]
-        # act(gate) * up is applied while down_proj stages its operand (reference :332-335)
         return self.down_proj(gate_up_states, act=1, partial=True)
 
     __call__ = forward

@@ -35,14 +35,14 @@ SIGNATURES = {
     "tgis_timing_reset": (_c_int, []),
     "tgis_timing_read": (_c_int, [_c_int, ctypes.POINTER(_c_i64), ctypes.POINTER(ctypes.c_double)]),
     "tgis_gptq_prepared_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
-    "tgis_gptq_prepare": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _vp, _vp]),
+    "tgis_gptq_prepare": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _vp]),
     "tgis_gptq_gemm_workspace_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
     "tgis_gptq_gemm_f16": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64,
                                     _c_int, _vp, _c_i64, _vp]),
     "tgis_gptq_gemm_partial_bytes": (_c_i64, [_c_i64, _c_i64]),
     "tgis_gptq_gemm_f16_partial": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_i64,
                                             ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64), _vp]),
-    "tgis_gptq_dequant_f16": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_i64, _vp]),
+    "tgis_gptq_dequant_f16": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp]),
     "tgis_dense_prepared_bytes": (_c_i64, [_c_i64, _c_i64]),
     "tgis_dense_prepare": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _vp, _vp]),
     "tgis_dense_gemm_workspace_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
@@ -167,7 +167,8 @@ class GptqWeight:
     """Prepared (repacked) GPTQ matrix; owner of the device image. Mirrors the q_handle of
     Ex4bitLinearV2.post_init (utils/gptq/exllamav2.py:124-137)."""
 
-    def __init__(self, qweight, qzeros, scales, g_idx, bits: int, groupsize: int):
+    def __init__(self, qweight, qzeros, scales, g_idx, bits: int, groupsize: int, gate_up: bool = False):
+        self.flags = 1 if gate_up else 0
         if bits != 4:
             raise TgisHipError("only 4-bit GPTQ is supported (exllamav2.py:105)")
         lib = load_library()
@@ -191,7 +192,7 @@ class GptqWeight:
         _check(
             lib.tgis_gptq_prepare(
                 _ptr(qweight), _ptr(qzeros), _ptr(scales), gi.data_ptr() if gi is not None else None,
-                _ptr(perm_buf), self.K, self.N, self.groups, _ptr(self.image), _stream()),
+                _ptr(perm_buf), self.K, self.N, self.groups, self.flags, _ptr(self.image), _stream()),
             "tgis_gptq_prepare")
         if gi is not None:
             gs = self.K // self.groups
@@ -205,12 +206,14 @@ class GptqWeight:
 
 
 def gptq_gemm(x: torch.Tensor, w: GptqWeight, ws: Workspace, bias=None, act: int = 0, out=None) -> torch.Tensor:
-    """out[M,N] = (act ? silu(x[:, :K]) * x[:, K:] : x) @ dequant(W) (+bias), f16."""
+    """act 0: out[M,N] = x @ dequant(W) (+bias); act 1: x is [M,2K], silu(x[:, :K]) * x[:, K:] is the operand;
+    act 2 (weight prepared with gate_up=True): out[M,N/2] = silu(gate) * up."""
     assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1
     M = x.shape[0]
-    assert x.shape[1] == (2 * w.K if act else w.K), (x.shape, w.K, act)
+    assert x.shape[1] == (2 * w.K if act == 1 else w.K), (x.shape, w.K, act)
+    assert act != 2 or w.flags & 1, "act=2 needs a weight prepared with gate_up=True"
     if out is None:
-        out = torch.empty((M, w.N), dtype=torch.float16, device=x.device)
+        out = torch.empty((M, w.N // 2 if act == 2 else w.N), dtype=torch.float16, device=x.device)
     ws.ensure(w.workspace_bytes(M))
     _check(
         load_library().tgis_gptq_gemm_f16(_ptr(x), x.stride(0), _ptr(w.image), _ptr(bias), _ptr(w.perm), _ptr(out),
@@ -251,7 +254,7 @@ def gptq_gemm_partial(x: torch.Tensor, w: GptqWeight, bias=None, act: int = 0) -
 def gptq_dequant(w: GptqWeight) -> torch.Tensor:
     """Dense f16 [K,N] (rows in the prepared order: permuted by w.perm for act-order matrices)."""
     out = torch.empty((w.K, w.N), dtype=torch.float16, device=w.image.device)
-    _check(load_library().tgis_gptq_dequant_f16(_ptr(w.image), _ptr(out), w.K, w.N, w.groups, _stream()),
+    _check(load_library().tgis_gptq_dequant_f16(_ptr(w.image), _ptr(out), w.K, w.N, w.groups, w.flags, _stream()),
            "tgis_gptq_dequant_f16")
     return out
 

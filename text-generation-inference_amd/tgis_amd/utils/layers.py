@@ -68,10 +68,12 @@ class Ex4bitLinearV2:
         # (no device check here: native.GptqWeight refuses tensors that are not on the GPU — server.py:290-291)
         assert self.height % 32 == 0 and self.width % 32 == 0
         self.q_handle: Optional[native.GptqWeight] = None
+        # set by LlamaMLP on the fused [gate | up] projection: SiLU(gate)*up runs in the GEMM epilogue
+        self.gate_up = False
 
     def post_init(self):
         self.q_handle = native.GptqWeight(self.qweight, self.qzeros, self.scales, self.g_idx, self.bits,
-                                          self.groupsize)
+                                          self.groupsize, gate_up=self.gate_up)
         self.qweight = self.qzeros = self.scales = None  # the prepared image replaces them
 
     def _dequant_scratch(self) -> torch.Tensor:
@@ -87,19 +89,27 @@ class Ex4bitLinearV2:
         """partial=True (decode-sized M only): return native.Partial — the consumer kernel finishes the split-K sum."""
         if self.q_handle is None:
             self.post_init()
+        if self.gate_up:
+            # output is the activated [M, I] tensor
+            if x.shape[0] <= SKINNY_MAX_M:
+                return native.gptq_gemm(x, self.q_handle, workspace(x.device), bias=self.bias, act=2)
+            return native.act_mul(self._large_m(x), self.width // 2)
         if partial and x.shape[0] <= 32 and DEFER_REDUCE:
             return native.gptq_gemm_partial(x, self.q_handle, bias=self.bias, act=act)
         if x.shape[0] <= SKINNY_MAX_M:
             return native.gptq_gemm(x, self.q_handle, workspace(x.device), bias=self.bias, act=act)
-        # prefill-sized M: dequantise once into scratch, then a library GEMM (exllamav2.py:87 "M > 50")
         if act:
             x = native.act_mul(x, self.height)
+        return self._large_m(x)
+
+    def _large_m(self, x: torch.Tensor) -> torch.Tensor:
+        """prefill-sized M: dequantise once into scratch, then a library GEMM (exllamav2.py:87 "M > 50")."""
         if self.q_handle.perm is not None:
             x = x.index_select(1, self.q_handle.perm.long())
         w = self._dequant_scratch()
         native._check(native.load_library().tgis_gptq_dequant_f16(
             self.q_handle.image.data_ptr(), w.data_ptr(), self.height, self.width, self.q_handle.groups,
-            native._stream()), "tgis_gptq_dequant_f16")
+            self.q_handle.flags, native._stream()), "tgis_gptq_dequant_f16")
         out = torch.matmul(x, w)
         if self.bias is not None:
             out.add_(self.bias)
