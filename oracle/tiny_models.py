@@ -132,3 +132,58 @@ def dense_state_dict(cfg, tensors: Dict[str, torch.Tensor], groupsize: int = 64)
         else:
             sd[name] = v.float()
     return sd
+
+
+class TinyBigCodeConfig:
+    model_type = "gpt_bigcode"
+
+    def __init__(self, vocab_size=256, hidden_size=256, n_inner=1024, num_hidden_layers=2, num_attention_heads=4,
+                 layer_norm_epsilon=1e-5, n_positions=512, activation_function="gelu_pytorch_tanh"):
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.n_inner = n_inner
+        self.num_hidden_layers = num_hidden_layers
+        self.num_attention_heads = num_attention_heads
+        self.layer_norm_epsilon = layer_norm_epsilon
+        self.n_positions = n_positions
+        self.activation_function = activation_function
+        self.multi_query = True
+        self.architectures = ["GPTBigCodeForCausalLM"]
+        self.transpose = False
+        self.pad_token_id = 0
+        self.bos_token_id = 1
+        self.eos_token_id = 2
+        self.tie_word_embeddings = True
+
+    def to_dict(self):
+        return {k: v for k, v in vars(self).items()}
+
+
+def tiny_bigcode_tensors(cfg, seed: int, dtype=torch.float16, embed_scale: float = 6.0) -> Dict[str, torch.Tensor]:
+    """HF GPTBigCode naming.  The head is tied to wte, so the embedding table is scaled up instead of the head to get
+    decisive greedy margins."""
+    g = torch.Generator().manual_seed(seed)
+    E, I, V = cfg.hidden_size, cfg.n_inner, cfg.vocab_size
+    D = E // cfg.num_attention_heads
+    t: Dict[str, torch.Tensor] = {}
+
+    def lin(name, n, k):
+        t[f"{name}.weight"] = (torch.randn(n, k, generator=g) * k ** -0.5).to(dtype)
+        t[f"{name}.bias"] = (torch.randn(n, generator=g) * 0.1).to(dtype)
+
+    def ln(name):
+        t[f"{name}.weight"] = (1.0 + 0.1 * torch.randn(E, generator=g)).to(dtype)
+        t[f"{name}.bias"] = (0.1 * torch.randn(E, generator=g)).to(dtype)
+
+    t["transformer.wte.weight"] = (torch.randn(V, E, generator=g) * embed_scale * E ** -0.5).to(dtype)
+    t["transformer.wpe.weight"] = (torch.randn(cfg.n_positions, E, generator=g) * 0.3).to(dtype)
+    for i in range(cfg.num_hidden_layers):
+        p = f"transformer.h.{i}"
+        ln(f"{p}.ln_1")
+        lin(f"{p}.attn.c_attn", E + 2 * D, E)
+        lin(f"{p}.attn.c_proj", E, E)
+        ln(f"{p}.ln_2")
+        lin(f"{p}.mlp.c_fc", I, E)
+        lin(f"{p}.mlp.c_proj", E, I)
+    ln("transformer.ln_f")
+    return t

@@ -29,7 +29,13 @@ REF = "/root/reference/server"
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "text-generation-inference_amd"))
 
-from oracle.tiny_models import TinyLlamaConfig, dense_state_dict, tiny_llama_tensors  # noqa: E402
+from oracle.tiny_models import (  # noqa: E402
+    TinyBigCodeConfig,
+    TinyLlamaConfig,
+    dense_state_dict,
+    tiny_bigcode_tensors,
+    tiny_llama_tensors,
+)
 
 
 def install_shims(tmp):
@@ -116,6 +122,31 @@ def write_model_dir(path, cfg, tensors, groupsize):
     sd = dense_state_dict(cfg, tensors, groupsize)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected and all("rotary" in m or "inv_freq" in m for m in missing), (missing, unexpected)
+    model.float().save_pretrained(path, safe_serialization=True)
+
+
+def write_bigcode_dir(path, cfg, tensors):
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import GPTBigCodeConfig, GPTBigCodeForCausalLM, PreTrainedTokenizerFast
+
+    vocab = {"<pad>": 0, "<s>": 1, "</s>": 2}
+    for i in range(3, cfg.vocab_size):
+        vocab[f"t{i}"] = i
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<pad>"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    PreTrainedTokenizerFast(tokenizer_object=tk, eos_token="</s>", bos_token="<s>", unk_token="<pad>",
+                            pad_token="<pad>").save_pretrained(path)
+    hf_cfg = GPTBigCodeConfig(vocab_size=cfg.vocab_size, n_embd=cfg.hidden_size, n_inner=cfg.n_inner,
+                              n_layer=cfg.num_hidden_layers, n_head=cfg.num_attention_heads,
+                              n_positions=cfg.n_positions, layer_norm_epsilon=cfg.layer_norm_epsilon,
+                              activation_function=cfg.activation_function, multi_query=True, attn_pdrop=0.0,
+                              resid_pdrop=0.0, embd_pdrop=0.0, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                              scale_attn_weights=True, attention_softmax_in_fp32=True, scale_attention_softmax_in_fp32=True)
+    model = GPTBigCodeForCausalLM(hf_cfg)
+    sd = {k: v.float() for k, v in tensors.items()}
+    sd["lm_head.weight"] = sd["transformer.wte.weight"]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all("bias" in m and "attn" in m or "masked_bias" in m for m in missing), (missing, unexpected)
     model.float().save_pretrained(path, safe_serialization=True)
 
 
@@ -221,6 +252,24 @@ def main():
              {**meta_base, "prompts_a": pa, "prompts_b": pb_, "max_new": 10,
               "script": ["prefill A(ids 0,1)", "decode A", "decode A", "prefill B(id 2, for_concat)",
                          "concatenate[A,B] + decode", "decode", "prune id 0 + decode", "decode"]}, steps)
+
+    # --- GPT-BigCode (multi-query attention, learned positions, LayerNorm, tanh-GELU, tied head) ------------------
+    bcfg = TinyBigCodeConfig()
+    btensors = tiny_bigcode_tensors(bcfg, seed=13, embed_scale=3.0)
+    mdir = os.path.join(tmp, "bigcode")
+    os.makedirs(mdir)
+    write_bigcode_dir(mdir, bcfg, btensors)
+    model = get_model(mdir, None, "hf_transformers", "float32", None, 256)
+    bmeta = {"variant": "bigcode", "seed": 13, "embed_scale": 3.0, "config": bcfg.to_dict(),
+             "transformers": __import__("transformers").__version__, "torch": torch.__version__}
+    prompts = [rng.integers(3, bcfg.vocab_size, size=12).tolist() for _ in range(3)]
+    batch = run_reference(model, make_requests(pb2, prompts, max_new=6))
+    steps = [step(model, batch, first=True)] + [step(model, batch) for _ in range(5)]
+    save("bigcode_equal", {**bmeta, "prompts": prompts, "max_new": 6}, steps)
+    prompts = [rng.integers(3, bcfg.vocab_size, size=n).tolist() for n in (4, 35, 18)]
+    batch = run_reference(model, make_requests(pb2, prompts, max_new=5))
+    steps = [step(model, batch, first=True)] + [step(model, batch) for _ in range(4)]
+    save("bigcode_ragged", {**bmeta, "prompts": prompts, "max_new": 5}, steps)
 
     # --- GPTQ pack pin: the reference's own packer vs oracle.ops_ref.gptq_pack on the same integers -----------
     from text_generation_server.utils.gptq.quant_linear import QuantLinear

@@ -93,3 +93,19 @@ def test_kv_page_layout_roundtrip():
                 vp[0, h, d * 32 + (i >> 2) * 8 + (tok >> 4) * 4 + (i & 3)] = V[tok, h, d]
     K2, V2 = ops_ref.kv_page_unpack(kp, vp, 0, Hkv, D)
     assert torch.equal(K2, K) and torch.equal(V2, V)
+
+
+@pytest.mark.parametrize("scenario", ["equal", "ragged"])
+def test_santacoder_oracle_matches_reference_generate(scenario):
+    """GPT-BigCode (MQA, learned positions, LayerNorm, tanh-GELU, tied head) through the reference's CPU path."""
+    from oracle.santacoder_ref import SantacoderRef
+    from oracle.tiny_models import TinyBigCodeConfig, tiny_bigcode_tensors
+
+    meta, steps = load_fixture(f"bigcode_{scenario}")
+    cfg = TinyBigCodeConfig()
+    ref = SantacoderRef(cfg, tiny_bigcode_tensors(cfg, seed=meta["seed"], embed_scale=meta["embed_scale"]))
+    got = ref.generate_greedy(meta["prompts"], len(steps), forced=[s["ids"].tolist() for s in steps])
+    for i, (g, w) in enumerate(zip(got, steps)):
+        np.testing.assert_allclose(g["logits"].numpy(), w["logits"], atol=LOGIT_ATOL, rtol=1e-4, err_msg=f"step {i}")
+        assert g["token_ids"].tolist() == w["ids"].tolist(), f"step {i}"
+        np.testing.assert_allclose(g["logprobs"].numpy(), w["logprobs"], atol=1e-4)

@@ -337,7 +337,7 @@ class FlashCausalLM(Model):
                 else:
                     tok.add_special_tokens({"pad_token": "[PAD]"})
 
-        inner = self.model.model
+        inner = self.model.model  # FlashLlamaModel / FlashSantacoderModel
         self.num_heads = inner.num_heads
         self.num_kv_heads = inner.num_key_value_heads
         self.head_size = inner.head_size
