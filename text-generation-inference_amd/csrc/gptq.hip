@@ -143,48 +143,56 @@ constexpr int KC = 256;     // k per LDS chunk (4 k64-steps)
 constexpr int RS = KC + 8;  // LDS row stride in halves (+16 B -> conflict-free ds_read_b128)
 constexpr int RING = 4;     // weight loads in flight per wave = one chunk ahead (4 KiB)
 
-// Streaming kernel: a block of WN waves owns 32*WN columns x [k0,k1) of W.  Each wave streams its own
-// 32-column tile (1 KiB per load, one chunk = 4 loads ahead) while the block double-buffers 32 x 256 chunks
-// of x through LDS.  The main loop is branch-free (clamped addresses + selects) so that hipcc keeps counted
-// vmcnt waits and the prefetched loads stay in flight across the per-chunk barrier.
+// Streaming kernel: a block of 4*WK waves owns 128 columns x [k0,k1) of W.  Wave w works on column tile
+// (w & 3) and k-part (w >> 2): it streams its own 32-column tile over its own contiguous KR/WK rows (1 KiB per
+// load, one chunk = 4 loads ahead) while each k-part group of 4 waves double-buffers its 32 x 256 chunks of x
+// through its own LDS region.  The WK partial accumulators are summed through LDS at the end (fixed order), so
+// in-block k-parts add waves per SIMD without slab traffic.  The main loop is branch-free (clamped addresses +
+// selects) so that hipcc keeps counted vmcnt waits and the prefetched loads stay in flight across the barriers.
 // GROUP64: group size is a multiple of 64 (one scale/zero per lane per step, prefetched with the weights).
-template <int WN, int ACT, bool GROUP64, bool PERM>
-__global__ __launch_bounds__(64 * WN) void gptq_gemm_kernel(GemmArgs a) {
-    constexpr int THREADS = 64 * WN;
-    constexpr int NJ = 1024 / THREADS;  // 16-byte x pieces per thread per chunk (32 rows x 32 pieces)
+// TN = column tiles (waves) per k-part: 4 (128 columns per block) or 2 (64 columns; more blocks for narrow N).
+template <int TN, int WK, int ACT, bool GROUP64, bool PERM>
+__global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
+    constexpr int GT = 64 * TN;      // threads of one k-part group
+    constexpr int NJ = 1024 / GT;    // 16-byte x pieces per thread per chunk (32 rows x 32 pieces per chunk)
+    constexpr int RSTEP = GT / 32;   // rows covered by one pass of the group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    f16* xs = reinterpret_cast<f16*>(smem);  // [2][32][RS]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wn = w % TN, wk = w / TN, ltid = tid % GT;
+    f16* xs = reinterpret_cast<f16*>(smem) + wk * (2 * 32 * RS);  // this k-part's [2][32][RS]
     const int ntg = blockIdx.x, split = blockIdx.y, mslab = blockIdx.z;
     const int m0 = mslab * 32;
     const int mrows = min(32, a.M - m0);
-    const int k0 = split * a.KR;
-    const int k1 = min(a.K, k0 + a.KR);
-    const int nchunks = (k1 - k0 + KC - 1) / KC;       // >= 1
-    const int last_step = nchunks * 4 - 1;              // image is padded to whole chunks
-    const int nt_raw = ntg * WN + w;
-    const int nt = min(nt_raw, a.NT - 1);               // out-of-range waves recompute the last tile, never store
+    const int krp = a.KR / WK;                           // rows per k-part (multiple of 256)
+    const int k0 = split * a.KR + wk * krp;
+    const int k1 = min(a.K, k0 + krp);                   // may be <= k0 for trailing k-parts: they add zeros
+    const int nchunks = krp / KC;                        // block-uniform trip count (same barriers for every wave)
+    const int nt_raw = ntg * TN + wn;
+    const int nt = min(nt_raw, a.NT - 1);                // out-of-range waves recompute the last tile, never store
     const int ks0 = k0 >> 6;
+    const int ks_last = a.KS - 2;                        // last real step of the image (KS includes one pad step)
     const int spg = a.G == 1 ? (1 << 30) : max(1, a.gs >> 6);  // k64-steps per group (GROUP64)
 
-    const u32x4* wptr = reinterpret_cast<const u32x4*>(a.prep) + ((int64_t)nt * a.KS + ks0) * 64 + lane;
+    const u32x4* wtile = reinterpret_cast<const u32x4*>(a.prep) + (int64_t)nt * a.KS * 64 + lane;
     const uint32_t* szp = reinterpret_cast<const uint32_t*>(a.prep + a.offB) + (int64_t)nt * a.G * 32 + (lane & 31);
     auto sz_at = [&](int step) -> uint32_t {
         int g = min((ks0 + step) / spg, a.G - 1);
         return szp[g * 32];
     };
+    auto w_at = [&](int step) -> u32x4 {
+        return __builtin_nontemporal_load(wtile + (int64_t)min(ks0 + step, ks_last) * 64);
+    };
     u32x4 wq[RING];
     uint32_t szr[RING];
 #pragma unroll
     for (int s = 0; s < RING; ++s) {
-        wq[s] = __builtin_nontemporal_load(wptr + s * 64);
+        wq[s] = w_at(s);
         if (GROUP64) szr[s] = sz_at(s);
     }
 
-    // ---- x staging: thread t handles rows (t / 32) + (THREADS/32) j, 16-byte column piece (t & 31) ----
+    // ---- x staging: local thread t handles rows (t / 32) + RSTEP j, 16-byte column piece (t & 31) ----
     const f16* xbase = a.x + (int64_t)m0 * a.ldx;
-    const int srow = tid >> 5, scol = (tid & 31) * 8;
-    constexpr int RSTEP = THREADS / 32;
+    const int srow = ltid >> 5, scol = (ltid & 31) * 8;
     f16x8 xg[NJ], xu[NJ];
     bool xok[NJ];
     auto stage_load = [&](int chunk) {
@@ -234,10 +242,10 @@ __global__ __launch_bounds__(64 * WN) void gptq_gemm_kernel(GemmArgs a) {
     uint32_t EXr = 0x64006400u, M0r = 0x000F000Fu, M1r = 0x00F000F0u;
     asm volatile("" : "+v"(EXr));
     asm volatile("" : "+s"(M0r), "+s"(M1r));
-    // four independent accumulators: the 4 MFMAs of a step do not wait on each other's 16-pass latency
-    f32x16 accs[4];
+    // two accumulators: consecutive MFMAs of a step alternate, halving the dependent-accumulator stalls
+    f32x16 accs[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) accs[i] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 2; ++i) accs[i] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int xoff = (lane & 31) * RS + (lane >> 5) * 32;
 
     stage_load(0);
@@ -246,13 +254,15 @@ __global__ __launch_bounds__(64 * WN) void gptq_gemm_kernel(GemmArgs a) {
     __builtin_amdgcn_s_barrier();
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        stage_load((a.dbg & 1) ? 0 : min(chunk + 1, nchunks - 1));  // last iteration restages its own chunk
+#ifndef ABL_NOSTAGE
+        stage_load(min(chunk + 1, nchunks - 1));  // last iteration restages its own chunk (unused)
+#endif
         // next chunk's scales: issued before this chunk's weight refills so that the loop-carried copy at the
         // bottom only needs vmcnt(#weight loads) and the weight stream stays in flight across the barrier
         uint32_t szn[RING];
         if (GROUP64) {
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) szn[s4] = sz_at(min(chunk * 4 + s4 + RING, last_step));
+            for (int s4 = 0; s4 < 4; ++s4) szn[s4] = sz_at(chunk * 4 + s4 + RING);
         }
         __builtin_amdgcn_sched_barrier(0);
         const f16* xbuf = xs + (chunk & 1) * (32 * RS) + xoff;
@@ -260,7 +270,6 @@ __global__ __launch_bounds__(64 * WN) void gptq_gemm_kernel(GemmArgs a) {
         for (int s4 = 0; s4 < 4; ++s4) {
             const int step = chunk * 4 + s4;
             const u32x4 cur = wq[s4];
-            const int nstep = (a.dbg & 2) ? 0 : min(step + RING, last_step);
             const f16* xk = xbuf + s4 * 64;
             f16x8 b[4];
             if (GROUP64) {
@@ -268,12 +277,17 @@ __global__ __launch_bounds__(64 * WN) void gptq_gemm_kernel(GemmArgs a) {
                 const f16 zc1 = szh[1];
                 const f16 zd1 = (f16)960.f - zc1;  // -(64 + z + 1), exact
                 const f16x2 zc = {zc1, zc1}, zd = {zd1, zd1}, sc = {szh[0], szh[0]};
+#ifdef ABL_NODEQ
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = __builtin_bit_cast(f16x8, u32x4{cur[i], cur[i] ^ EXr, cur[i], cur[i]});
+#else
 #pragma unroll
                 for (int i = 0; i < 4; ++i) b[i] = dequant8(cur[i], zc, zd, sc, EXr, M0r, M1r);
+#endif
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    int k = ((ks0 + step) * 8 + (lane >> 5) * 4 + i) * 8;
+                    int k = (min(ks0 + step, ks_last) * 8 + (lane >> 5) * 4 + i) * 8;
                     int g = min(k / a.gs, a.G - 1);
                     f16x2 szh = __builtin_bit_cast(f16x2, szp[g * 32]);
                     f16 zc1 = szh[1], zd1 = (f16)960.f - zc1;
@@ -283,15 +297,23 @@ __global__ __launch_bounds__(64 * WN) void gptq_gemm_kernel(GemmArgs a) {
             }
             // slot s4 is consumed: refill it in place for the next chunk (no register copy at the back-edge)
             __builtin_amdgcn_sched_barrier(0);
-            wq[s4] = __builtin_nontemporal_load(wptr + nstep * 64);
+            wq[s4] = w_at(step + RING);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+#if defined(ABL_NOMFMA)
+                accs[i & 1][0] += (float)b[i][0] + (float)b[i][7];
+#elif defined(ABL_NOLDSREAD)
+                accs[i & 1] = mfma32(b[(i + 1) & 3], b[i], accs[i & 1]);
+#else
                 f16x8 av = ld16<f16x8>(xk + i * 8);
-                accs[i] = mfma32(av, b[i], accs[i]);
+                accs[i & 1] = mfma32(av, b[i], accs[i & 1]);
+#endif
             }
         }
+#ifndef ABL_NOSTAGE
         stage_store((chunk + 1) & 1);
+#endif
         if (GROUP64) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) szr[s4] = szn[s4];
@@ -300,9 +322,35 @@ __global__ __launch_bounds__(64 * WN) void gptq_gemm_kernel(GemmArgs a) {
         __builtin_amdgcn_s_barrier();
     }
 
+    f32x16 acc = accs[0] + accs[1];
+    // ---- sum the WK k-parts through LDS (fixed order => deterministic) --------------------------------
+    if (WK > 1) {
+        float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][64 lanes][16]; the x buffers are dead now
+        if (wk > 0) {
+            float* dst = red + (((wk * TN + wn) * 64 + lane) << 4);
+#pragma unroll
+            for (int r = 0; r < 16; r += 4)
+                *reinterpret_cast<f32x4*>(dst + r) = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wk > 0) return;
+#pragma unroll
+        for (int k2 = 1; k2 < WK; ++k2) {
+            const float* src = red + (((k2 * TN + wn) * 64 + lane) << 4);
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(src + r);
+                acc[r] += t[0];
+                acc[r + 1] += t[1];
+                acc[r + 2] += t[2];
+                acc[r + 3] += t[3];
+            }
+        }
+    }
+
     // ---- epilogue: lane holds out[m = (r&3)+8(r>>2)+4(lane>>5)][n = nt*32 + (lane&31)] ------------
     if (nt_raw >= a.NT) return;
-    const f32x16 acc = (accs[0] + accs[1]) + (accs[2] + accs[3]);
     const int n = nt * 32 + (lane & 31);
     if (ACT == 2) {
         // columns are interleaved gate/up pairs (col_src flags bit 0): lanes c < 16 hold gate column j = 16 nt + c,
@@ -393,33 +441,35 @@ __global__ void gptq_dequant_kernel(const uint8_t* __restrict__ prep, int64_t of
 }
 
 struct GemmPlan {
-    int KR, S, WN;
+    int KR, S, WK, TN;  // rows per block, global k splits, in-block k-parts, column tiles per k-part
 };
 
-// Block = 128 columns x KR rows.  More splits = more blocks in flight but S*M*N*8 bytes of slab traffic
-// and a reduce launch; a wave should stream >= 16 KiB to amortise its prologue/epilogue.
-static GemmPlan plan_gemm(int64_t K, int64_t N) {
-    if (const char* ov = getenv("TGIS_GPTQ_PLAN")) {  // tuning hook: "KR,S,WN"
-        int kr = 0, sp = 0, wn = 0;
-        if (sscanf(ov, "%d,%d,%d", &kr, &sp, &wn) == 3 && kr > 0 && kr % KC == 0 && (int64_t)sp * kr >= K &&
-            (int64_t)(sp - 1) * kr < K && (wn == 4 || wn == 8))
-            return {kr, sp, wn};
+// Block = 32*TN columns x KR rows, TN*WK waves (KR a multiple of 256*WK).  Measured on MI355X
+// (profiles/r01_gemm_pmc.md): weight streaming alone runs at ~3.3 TB/s for these sizes and dequant + MFMA add on
+// top rather than hide, so the plan first spreads the matrix over all 256 CUs (narrow blocks before global
+// k-splits, which cost slab traffic), then adds in-block k-parts (free of slab traffic) for waves per SIMD.
+static GemmPlan plan_gemm(int64_t K, int64_t N, int act = 0) {
+    if (const char* ov = getenv("TGIS_GPTQ_PLAN")) {  // tuning hook: "KR,S,WK,TN"
+        int kr = 0, sp = 0, wk = 0, tn = 0;
+        if (sscanf(ov, "%d,%d,%d,%d", &kr, &sp, &wk, &tn) == 4 && kr > 0 && (wk == 1 || wk == 2 || wk == 4) &&
+            (tn == 2 || tn == 4) && !(tn == 2 && wk == 1) && kr % (KC * wk) == 0 && (int64_t)sp * kr >= K &&
+            (int64_t)(sp - 1) * kr < K && (act != 2 || sp == 1))
+            return {kr, sp, wk, tn};
     }
-    const int WN = 4;
     const int64_t tiles = cdiv64(N, 32);
-    const int64_t colblocks = cdiv64(tiles, WN);
     const int64_t kchunks = cdiv64(K, KC);
-    // Measured on MI355X (tools/sweep_gptq.py, profiles/): the kernel is bound by per-step instruction
-    // issue, not by HBM, so extra splits only add slab traffic and a reduce launch.  Take the smallest S
-    // that puts a wave on most SIMDs (>= 680 waves) while each wave still streams >= 2 chunks.
-    GemmPlan best = {(int)(kchunks * KC), 1, WN};
-    for (int64_t S = 1; S <= kchunks; ++S) {
-        int64_t KRc = cdiv64(kchunks, S);
-        if ((S - 1) * KRc >= kchunks) continue;  // empty last split
-        best = {(int)(KRc * KC), (int)S, WN};
-        if (tiles * S >= (kchunks > 16 ? 1000 : 680) || KRc <= 2) break;
+    int TN = tiles >= 512 ? 4 : 2;  // measured: wide N is best with 128-column blocks, narrow N with 64
+    int64_t colblocks = cdiv64(tiles, TN);
+    int64_t S = 1;
+    if (act != 2 && colblocks < 224) {  // the SiLU epilogue needs the complete sum in one block
+        S = std::max<int64_t>(1, std::min<int64_t>(kchunks, (256 + colblocks / 2) / colblocks));
+        while (S > 1 && (S - 1) * cdiv64(kchunks, S) >= kchunks) --S;  // no empty last split
     }
-    return best;
+    int64_t KRc = cdiv64(kchunks, S);
+    int WK = KRc >= 4 ? 4 : 2;
+    KRc = cdiv64(KRc, WK) * WK;  // whole chunks per k-part (rows beyond K contribute zeros)
+    while (S > 1 && (S - 1) * KRc >= kchunks) --S;
+    return {(int)(KRc * KC), (int)S, WK, TN};
 }
 
 static int64_t slab_bytes(int64_t M, int64_t N, int S) {
@@ -513,16 +563,31 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
         const char* d = getenv("TGIS_GPTQ_DBG");
         a.dbg = d ? atoi(d) : 0;
     }
-    dim3 grid((unsigned)cdiv64(p.NT, pl.WN), (unsigned)pl.S, (unsigned)mslabs);
-    const size_t lds = 2 * 32 * RS * sizeof(f16);
-#define TGIS_LAUNCH_GEMM(W, A, G, P) \
-    hipLaunchKernelGGL((gptq_gemm_kernel<W, A, G, P>), grid, dim3(64 * W), lds, st, a)
-#define TGIS_LAUNCH_GEMM_W(A, G, P)             \
-    do {                                        \
-        if (pl.WN == 8)                         \
-            TGIS_LAUNCH_GEMM(8, A, G, P);       \
-        else                                    \
-            TGIS_LAUNCH_GEMM(4, A, G, P);       \
+    dim3 grid((unsigned)cdiv64(p.NT, pl.TN), (unsigned)pl.S, (unsigned)mslabs);
+    const size_t lds = (size_t)pl.WK * 2 * 32 * RS * sizeof(f16);
+#define TGIS_LAUNCH_GEMM(T, W, A, G, P)                                                                       \
+    do {                                                                                                      \
+        static bool attr_done = false;                                                                        \
+        if (!attr_done) {                                                                                     \
+            TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_gemm_kernel<T, W, A, G, P>,                  \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * RS * 2)); \
+            attr_done = true;                                                                                 \
+        }                                                                                                     \
+        hipLaunchKernelGGL((gptq_gemm_kernel<T, W, A, G, P>), grid, dim3(64 * T * W), lds, st, a);            \
+    } while (0)
+#define TGIS_LAUNCH_GEMM_W(A, G, P)                      \
+    do {                                                 \
+        const int tw = pl.TN * 10 + pl.WK;               \
+        if (tw == 44)                                    \
+            TGIS_LAUNCH_GEMM(4, 4, A, G, P);             \
+        else if (tw == 42)                               \
+            TGIS_LAUNCH_GEMM(4, 2, A, G, P);             \
+        else if (tw == 41)                               \
+            TGIS_LAUNCH_GEMM(4, 1, A, G, P);             \
+        else if (tw == 24)                               \
+            TGIS_LAUNCH_GEMM(2, 4, A, G, P);             \
+        else                                             \
+            TGIS_LAUNCH_GEMM(2, 2, A, G, P);             \
     } while (0)
     const int variant = (act == 1 ? 4 : act == 2 ? 8 : 0) | (group64 ? 2 : 0) | (perm ? 1 : 0);
     switch (variant) {
@@ -572,8 +637,7 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
     TGIS_CHECK_ARG(out, "tgis_gptq_gemm_f16: null out");
     if (M == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
-    GemmPlan pl = plan_gemm(K, N);
-    if (act == 2) pl = {(int)(cdiv64(K, KC) * KC), 1, pl.WN};  // the nonlinearity needs the complete sum
+    GemmPlan pl = plan_gemm(K, N, act);
     TGIS_CHECK_ARG(cdiv64(M, 32) <= 65535, "tgis_gptq_gemm_f16: M too large for one launch");
     int64_t need = 4096 + slab_bytes(M, N, pl.S);
     TGIS_CHECK_ARG(workspace && workspace_bytes >= need, "tgis_gptq_gemm_f16: workspace too small (%ld < %ld)",
@@ -606,13 +670,17 @@ extern "C" int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void
 }
 
 // debug aid (not part of the documented ABI): resident blocks per CU the runtime reports for the main kernel
-extern "C" int tgis_debug_gemm_occupancy(int wn) {
+extern "C" int tgis_debug_gemm_occupancy(int tn, int wk) {
     int nb = -1;
-    const size_t lds = 2 * 32 * RS * sizeof(f16);
-    if (wn == 8)
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<8, 0, true, false>, 512, lds);
+    const size_t lds = (size_t)wk * 2 * 32 * RS * sizeof(f16);
+    if (tn == 4 && wk == 4)
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<4, 4, 0, true, false>, 1024, lds);
+    else if (tn == 2 && wk == 4)
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<2, 4, 0, true, false>, 512, lds);
+    else if (tn == 2 && wk == 2)
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<2, 2, 0, true, false>, 256, lds);
     else
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<4, 0, true, false>, 256, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<4, 1, 0, true, false>, 256, lds);
     return nb;
 }
 

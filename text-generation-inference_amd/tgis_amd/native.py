@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtgis_hip.so")
+LIB_PATH = os.getenv("TGIS_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libtgis_hip.so")
 
 F16, BF16 = 0, 1
 KV_PAGE_TOKENS = 32

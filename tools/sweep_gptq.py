@@ -1,10 +1,10 @@
 import os, subprocess, sys
 shapes = [(4096, 12288), (4096, 4096), (4096, 22016), (11008, 4096)]
 plans = {
- (4096,12288): ["4096,1,4","2048,2,4","1024,4,4","512,8,4","2048,2,8","1024,4,8","512,8,8","256,16,8"],
- (4096,4096): ["2048,2,4","1024,4,4","512,8,4","256,16,4","1024,4,8","512,8,8","256,16,8"],
- (4096,22016): ["4096,1,4","2048,2,4","1024,4,4","2048,2,8","1024,4,8","512,8,8"],
- (11008,4096): ["2816,4,4","1536,8,4","1024,11,4","768,15,4","1536,8,8","1024,11,8","768,15,8","512,22,8"],
+ (4096,12288): ["2048,2,4,2","4096,1,4,2","2048,2,2,2","2048,2,4,4","1024,4,4,2"],
+ (4096,4096): ["1024,4,4,2","1024,4,2,2","512,8,2,4","2048,2,4,2","512,8,2,2"],
+ (4096,22016): ["4096,1,4,2","4096,1,2,2","4096,1,4,4","4096,1,1,4"],
+ (11008,4096): ["3072,4,4,2","2048,6,4,2","1536,8,2,2","1536,8,2,4"],
 }
 code = '''
 import sys, torch
