@@ -11,6 +11,7 @@
 //   O^T[d][col]  += V^T[d][tok] . P^T[tok][col] A = V^T fragment (1 KiB contiguous loads), B = P^T
 // S^T's accumulator layout IS the B-operand layout of the second MFMA and O^T's column index is the
 // same lane, so the only cross-lane traffic per page is the 2-step row-max exchange.
+#include <stdlib.h>
 #include <algorithm>
 #include "common.h"
 
@@ -34,8 +35,9 @@ struct AttnArgs {
 
 constexpr float NEG_BIG = -1.0e30f;
 
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_paged_kernel(AttnArgs a) {
+// NW = waves per workgroup (the key range of a block is dealt page-by-page to its waves)
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     using V8 = typename VecT<T>::x8;
     constexpr int KS = D / 32;  // k-steps of the QK^T MFMA
     constexpr int NB = D / 16;  // 16-row blocks of O^T
@@ -83,8 +85,8 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(AttnArgs a) {
     const int32_t* btrow = a.bt + (int64_t)b * a.max_pages;
     int p = pbeg + w;
     int pg = (p < pend) ? btrow[p] : 0;
-    for (; p < pend; p += 4) {
-        const int pg_next = (p + 4 < pend) ? btrow[p + 4] : 0;
+    for (; p < pend; p += NW) {
+        const int pg_next = (p + NW < pend) ? btrow[p + NW] : 0;
         const T* kb = reinterpret_cast<const T*>(a.kpool) + ((int64_t)pg * a.Hkv + hk) * (32 * D) + lane * 8;
         const T* vb = reinterpret_cast<const T*>(a.vpool) + ((int64_t)pg * a.Hkv + hk) * (32 * D) + col * 32 + c * 8;
         V8 kf[2][KS], vf[NB];
@@ -144,8 +146,8 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(AttnArgs a) {
     // ---- combine the 4 waves through LDS ----------------------------------------------------------
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
-    float* so = reinterpret_cast<float*>(smem);          // [4][D][16]
-    float* sml = so + 4 * D * 16;                        // [4][2][16]
+    float* so = reinterpret_cast<float*>(smem);          // [NW][D][16]
+    float* sml = so + NW * D * 16;                       // [NW][2][16]
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -156,19 +158,19 @@ __global__ __launch_bounds__(256) void attn_paged_kernel(AttnArgs a) {
     }
     __syncthreads();
     // thread -> (column j, 8 consecutive d)
-    for (int item = tid; item < 16 * (D / 8); item += 256) {
+    for (int item = tid; item < 16 * (D / 8); item += 64 * NW) {
         const int j = item & 15, dc = item >> 4;
         const int tqj = j / a.Gp, gj = j % a.Gp;
         if (!(gj < a.Gc && hc * 16 + gj < a.G && t0 + tqj < q_len)) continue;
-        float mw[4], mstar = NEG_BIG;
+        float mw[NW], mstar = NEG_BIG;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NW; ++k) {
             mw[k] = sml[(k * 2) * 16 + j];
             mstar = fmaxf(mstar, mw[k]);
         }
         float l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NW; ++k) {
             float f = exp2f(mw[k] - mstar);
             l += sml[(k * 2 + 1) * 16 + j] * f;
 #pragma unroll
@@ -237,9 +239,14 @@ static AttnGeom geom(int H, int Hkv) {
 }
 
 template <typename T, int D>
-static int launch_attn(const AttnArgs& a, dim3 grid, int64_t total_q, hipStream_t st) {
-    const size_t lds = (4 * D * 16 + 4 * 2 * 16) * sizeof(float);
-    hipLaunchKernelGGL((attn_paged_kernel<T, D>), grid, dim3(256), lds, st, a);
+static int launch_attn(const AttnArgs& a, dim3 grid, int64_t total_q, hipStream_t st, int nw) {
+    const size_t lds = (size_t)(nw * D * 16 + nw * 2 * 16) * sizeof(float);
+    if (nw == 1)
+        hipLaunchKernelGGL((attn_paged_kernel<T, D, 1>), grid, dim3(64), lds, st, a);
+    else if (nw == 2)
+        hipLaunchKernelGGL((attn_paged_kernel<T, D, 2>), grid, dim3(128), lds, st, a);
+    else
+        hipLaunchKernelGGL((attn_paged_kernel<T, D, 4>), grid, dim3(256), lds, st, a);
     TGIS_CHECK_LAUNCH();
     if (a.NS > 1) {
         hipLaunchKernelGGL((attn_combine_kernel<T, D>), dim3((unsigned)(total_q * a.H)), dim3(64), 0, st, a.ws_o,
@@ -320,12 +327,16 @@ extern "C" int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, 
     TGIS_CHECK_ARG(q_tiles <= 2147483647LL && (int64_t)Hkv * g.HC <= 65535 && B * num_splits <= 65535,
                    "tgis_attn_paged: grid too large");
     dim3 grid((unsigned)q_tiles, (unsigned)(Hkv * g.HC), (unsigned)(B * num_splits));
+    // waves per block: with >= 1024 (sequence, kv head) blocks the chip is full either way and 2-wave blocks halve
+    // the page-count imbalance between a block's waves (33 pages over 4 waves = 9/8/8/8; over 2 = 17/16)
+    int nw = (max_q_len == 1 && (int64_t)grid.x * grid.y * grid.z >= 1024) ? 2 : 4;
+    if (const char* e = getenv("TGIS_ATTN_NW")) nw = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 4;
     TgisTimedScope timed(TGIS_OP_ATTN, st);
     if (dtype == TGIS_F16) {
-        if (D == 128) return launch_attn<f16, 128>(a, grid, total_q, st);
-        return launch_attn<f16, 64>(a, grid, total_q, st);
+        if (D == 128) return launch_attn<f16, 128>(a, grid, total_q, st, nw);
+        return launch_attn<f16, 64>(a, grid, total_q, st, nw);
     } else {
-        if (D == 128) return launch_attn<bf16, 128>(a, grid, total_q, st);
-        return launch_attn<bf16, 64>(a, grid, total_q, st);
+        if (D == 128) return launch_attn<bf16, 128>(a, grid, total_q, st, nw);
+        return launch_attn<bf16, 64>(a, grid, total_q, st, nw);
     }
 }
