@@ -91,13 +91,13 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// Sum of S split-K slabs for 8 consecutive columns: all loads are issued before the first add (a runtime-trip
-// loop would serialise one L2 round trip per slab).  stride = elements between slabs.
-__device__ __forceinline__ void sum_slabs8(const float* sp, int64_t stride, int S, f32x4& lo, f32x4& hi) {
-    constexpr int MAXS = 8;
-    f32x4 l[MAXS], h[MAXS];
+// Sum of S split-K slabs for 8 consecutive columns: all loads of a bucket are issued before the first add (a
+// runtime-trip loop would serialise one L2 round trip per slab).  stride = elements between slabs.
+template <int SB>
+__device__ __forceinline__ void sum_slabs_bucket(const float* sp, int64_t stride, int S, f32x4& lo, f32x4& hi) {
+    f32x4 l[SB], h[SB];
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s) {
+    for (int s = 0; s < SB; ++s) {
         const float* q = sp + (int64_t)min(s, S - 1) * stride;
         l[s] = *reinterpret_cast<const f32x4*>(q);
         h[s] = *reinterpret_cast<const f32x4*>(q + 4);
@@ -105,16 +105,26 @@ __device__ __forceinline__ void sum_slabs8(const float* sp, int64_t stride, int 
     lo = l[0];
     hi = h[0];
 #pragma unroll
-    for (int s = 1; s < MAXS; ++s) {
+    for (int s = 1; s < SB; ++s) {
         if (s < S) {
             lo += l[s];
             hi += h[s];
         }
     }
-    for (int s = MAXS; s < S; ++s) {
+    for (int s = SB; s < S; ++s) {
         lo += *reinterpret_cast<const f32x4*>(sp + (int64_t)s * stride);
         hi += *reinterpret_cast<const f32x4*>(sp + (int64_t)s * stride + 4);
     }
+}
+__device__ __forceinline__ void sum_slabs8(const float* sp, int64_t stride, int S, f32x4& lo, f32x4& hi) {
+    if (S <= 1)
+        sum_slabs_bucket<1>(sp, stride, S, lo, hi);
+    else if (S <= 2)
+        sum_slabs_bucket<2>(sp, stride, S, lo, hi);
+    else if (S <= 4)
+        sum_slabs_bucket<4>(sp, stride, S, lo, hi);
+    else
+        sum_slabs_bucket<8>(sp, stride, S, lo, hi);
 }
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -8,28 +8,33 @@
 
 namespace {
 
-constexpr int NT = 256;
-constexpr int MAXV = 8;  // 8 x (256 threads x 8 elems) = 16384 max hidden
+constexpr int MAX_HIDDEN = 16384;
 
+template <int NT>
 __device__ __forceinline__ float block_sum(float v, float* sh) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) sh[w] = v;
     __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) t += sh[k];
+    return t;
 }
 
 // x either as a model-dtype tensor, or (PARTIAL) as S fp32 split-K slabs [S][32][slab_ld] whose sum (+xbias) is
 // rounded to the model dtype first — bit-identical to running the split-K reduce kernel and then this one.
-template <typename T, bool RMS, bool PARTIAL>
+// NT threads per row: 256 in general, 512 for decode-sized batches (few rows: latency matters, not occupancy)
+template <typename T, bool RMS, bool PARTIAL, int NT>
 __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
                                                   const T* __restrict__ weight, const T* __restrict__ bias,
                                                   T* y, T* res_out, int hidden,
                                                   float eps, const float* __restrict__ slabs, int S, int64_t slab_ld,
                                                   const T* __restrict__ xbias) {
     using V8 = typename VecT<T>::x8;
-    __shared__ float sh[4];
+    constexpr int MAXV = MAX_HIDDEN / (NT * 8);
+    __shared__ float sh[NT / 64];
     const int64_t row = blockIdx.x;
     const T* xr = PARTIAL ? nullptr : x + row * hidden;
     const T* rr = residual ? residual + row * hidden : nullptr;
@@ -80,10 +85,10 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
     }
     float mean = 0.f, rstd;
     if (RMS) {
-        float tot = block_sum(s2, sh);
+        float tot = block_sum<NT>(s2, sh);
         rstd = rsqrtf(tot / hidden + eps);
     } else {
-        mean = block_sum(s1, sh) / hidden;
+        mean = block_sum<NT>(s1, sh) / hidden;
         float d2 = 0.f;
 #pragma unroll
         for (int it = 0; it < MAXV; ++it) {
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
                 }
             }
         }
-        float var = block_sum(d2, sh) / hidden;
+        float var = block_sum<NT>(d2, sh) / hidden;
         rstd = rsqrtf(var + eps);
     }
 #pragma unroll
@@ -126,16 +131,24 @@ static int launch_norm(const void* x, const void* residual, const void* weight, 
     TGIS_CHECK_ARG((x || slabs) && weight && y, "norm: null tensor");
     TGIS_CHECK_ARG(!slabs || (rows <= 32 && S >= 1 && slab_ld >= hidden && slab_ld % 4 == 0),
                    "norm: partial input needs rows <= 32 and a slab row stride >= hidden");
-    TGIS_CHECK_ARG(hidden > 0 && hidden % 8 == 0 && hidden <= NT * 8 * MAXV,
-                   "norm: hidden (%ld) must be a multiple of 8 and <= %d", (long)hidden, NT * 8 * MAXV);
+    TGIS_CHECK_ARG(hidden > 0 && hidden % 8 == 0 && hidden <= MAX_HIDDEN,
+                   "norm: hidden (%ld) must be a multiple of 8 and <= %d", (long)hidden, MAX_HIDDEN);
     TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "norm: bad dtype");
     if (rows == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
     TgisTimedScope timed(TGIS_OP_NORM, st);
-#define TGIS_NORM_LAUNCH(T, P)                                                                              \
-    hipLaunchKernelGGL((norm_kernel<T, RMS, P>), dim3((unsigned)rows), dim3(NT), 0, st, (const T*)x,             \
-                       (const T*)residual, (const T*)weight, (const T*)bias, (T*)y, (T*)res_out, (int)hidden, eps, \
-                       slabs, S, slab_ld, (const T*)xbias)
+    const bool wide = rows <= 64 && hidden >= 2048;
+#define TGIS_NORM_LAUNCH(T, P)                                                                                   \
+    do {                                                                                                         \
+        if (wide)                                                                                                \
+            hipLaunchKernelGGL((norm_kernel<T, RMS, P, 512>), dim3((unsigned)rows), dim3(512), 0, st, (const T*)x, \
+                               (const T*)residual, (const T*)weight, (const T*)bias, (T*)y, (T*)res_out,         \
+                               (int)hidden, eps, slabs, S, slab_ld, (const T*)xbias);                            \
+        else                                                                                                     \
+            hipLaunchKernelGGL((norm_kernel<T, RMS, P, 256>), dim3((unsigned)rows), dim3(256), 0, st, (const T*)x, \
+                               (const T*)residual, (const T*)weight, (const T*)bias, (T*)y, (T*)res_out,         \
+                               (int)hidden, eps, slabs, S, slab_ld, (const T*)xbias);                            \
+    } while (0)
     if (dtype == TGIS_F16) {
         if (slabs) TGIS_NORM_LAUNCH(f16, true); else TGIS_NORM_LAUNCH(f16, false);
     } else {
