@@ -16,6 +16,7 @@
 #include <numeric>
 #include <vector>
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -136,12 +137,26 @@ struct GemmArgs {
     int NT, KS;
     float* slabs;  // [Mslabs][S][32][NT*32] f32 partial sums (S > 1 or partial mode)
     int partial;   // 1: always leave fp32 slabs (deferred reduce), never write `out`
-    int dbg;       // tuning hook (TGIS_GPTQ_DBG): 1 = restage x chunk 0 only, 2 = reload weight step 0 only
+    int spg_shift; // GROUP64: log2(k64-steps per group) (30 when there is a single group)
 };
+
+#ifdef TGIS_TRACE
+__device__ long long* g_trace = nullptr;  // [blocks][16 waves][32 stamps] of s_memtime (debug builds only)
+#define TRACE(i)                                                                                            \
+    do {                                                                                                    \
+        if (g_trace) /* every lane stores the same stamp: no divergent branch, the SGPR pins stay legal */  \
+            g_trace[((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 +       \
+                     __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define TRACE(i)
+#endif
+
+#define GLOBAL_AS __attribute__((address_space(1)))  // asm-pinned pointers lose their address space: restate it
+#define PIN_SGPR(p) asm volatile("" : "+s"(p))
 
 constexpr int KC = 256;     // k per LDS chunk (4 k64-steps)
 constexpr int RS = KC + 8;  // LDS row stride in halves (+16 B -> conflict-free ds_read_b128)
-constexpr int RING = 4;     // weight loads in flight per wave = one chunk ahead (4 KiB)
 
 // Streaming kernel: a block of 4*WK waves owns 128 columns x [k0,k1) of W.  Wave w works on column tile
 // (w & 3) and k-part (w >> 2): it streams its own 32-column tile over its own contiguous KR/WK rows (1 KiB per
@@ -153,12 +168,20 @@ constexpr int RING = 4;     // weight loads in flight per wave = one chunk ahead
 // TN = column tiles (waves) per k-part: 4 (128 columns per block) or 2 (64 columns; more blocks for narrow N).
 template <int TN, int WK, int ACT, bool GROUP64, bool PERM>
 __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
-    constexpr int GT = 64 * TN;      // threads of one k-part group
-    constexpr int NJ = 1024 / GT;    // 16-byte x pieces per thread per chunk (32 rows x 32 pieces per chunk)
-    constexpr int RSTEP = GT / 32;   // rows covered by one pass of the group
+    // one chunk (4 one-KiB loads) of weights in flight per wave.  Measured: a two-chunk ring is ~1 us SLOWER on every
+    // cfg3 shape (the first barrier waits for twice the prologue loads to issue; HBM is not the limiter afterwards)
+    constexpr int RING = 4;
+    constexpr int GT = 64 * TN;                 // threads of one k-part group
+    constexpr int NJ = (1024 + GT - 1) / GT;    // 16-byte x pieces per thread per chunk (32 rows x 32 pieces per chunk)
+    constexpr int RSTEP = GT / 32;              // rows covered by one pass of the group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wn = w % TN, wk = w / TN, ltid = tid % GT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index and everything derived from it (tile, k-range, image addresses) is wave-uniform: keep it in
+    // SGPRs so that the address/clamp arithmetic of the loop runs on the scalar unit, not on the VALU that the
+    // dequantisation saturates
+    TRACE(0);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w % TN, wk = w / TN, ltid = wn * 64 + lane;
     f16* xs = reinterpret_cast<f16*>(smem) + wk * (2 * 32 * RS);  // this k-part's [2][32][RS]
     const int ntg = blockIdx.x, split = blockIdx.y, mslab = blockIdx.z;
     const int m0 = mslab * 32;
@@ -171,43 +194,49 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
     const int nt = min(nt_raw, a.NT - 1);                // out-of-range waves recompute the last tile, never store
     const int ks0 = k0 >> 6;
     const int ks_last = a.KS - 2;                        // last real step of the image (KS includes one pad step)
-    const int spg = a.G == 1 ? (1 << 30) : max(1, a.gs >> 6);  // k64-steps per group (GROUP64)
 
-    const u32x4* wtile = reinterpret_cast<const u32x4*>(a.prep) + (int64_t)nt * a.KS * 64 + lane;
-    const uint32_t* szp = reinterpret_cast<const uint32_t*>(a.prep + a.offB) + (int64_t)nt * a.G * 32 + (lane & 31);
-    auto sz_at = [&](int step) -> uint32_t {
-        int g = min((ks0 + step) / spg, a.G - 1);
-        return szp[g * 32];
+    const char* wtile = reinterpret_cast<const char*>(a.prep) + (int64_t)nt * a.KS * 1024;
+    const char* sztile = reinterpret_cast<const char*>(a.prep + a.offB) + (int64_t)nt * a.G * 128;
+    const uint32_t woff = lane * 16, szoff = (lane & 31) * 4;
+    // prefetches past this wave's rows re-read its own last step (a cache hit), not the next k-part's rows
+    const int ks_clamp = min(ks_last, max(ks0, (k1 >> 6) - 1));
+    const int ks_end = k1 >> 6;  // first step past this wave's rows: its scale is forced to zero (GROUP64: K % 64 == 0)
+    auto sz_at = [&](int step) -> uint32_t {   // GROUP64: one {scale, zero} pair per lane and k64-step
+        const int g = min((ks0 + step) >> a.spg_shift, a.G - 1);
+        const char* p = sztile + (int64_t)g * 128;
+        PIN_SGPR(p);  // keep the wave-uniform base in SGPRs: the load takes (sgpr base + lane offset)
+        const uint32_t v = *(const GLOBAL_AS uint32_t*)(p + szoff);
+        return ks0 + step < ks_end ? v : 0u;   // zero scale: x columns past k1 are never masked, their weights are
     };
     auto w_at = [&](int step) -> u32x4 {
-        return __builtin_nontemporal_load(wtile + (int64_t)min(ks0 + step, ks_last) * 64);
+        const char* p = wtile + (int64_t)min(ks0 + step, ks_clamp) * 1024;
+        PIN_SGPR(p);
+        return __builtin_nontemporal_load((const GLOBAL_AS u32x4*)(p + woff));
     };
-    u32x4 wq[RING];
-    uint32_t szr[RING];
-#pragma unroll
-    for (int s = 0; s < RING; ++s) {
-        wq[s] = w_at(s);
-        if (GROUP64) szr[s] = sz_at(s);
-    }
+    const uint32_t* szp = reinterpret_cast<const uint32_t*>(sztile + szoff);
 
     // ---- x staging: local thread t handles rows (t / 32) + RSTEP j, 16-byte column piece (t & 31) ----
+    // Rows past M and columns past k1 are loaded from clamped (valid, finite) addresses and never masked: a row only
+    // feeds its own output row, and the weights of steps past k1 carry a zero scale.
     const f16* xbase = a.x + (int64_t)m0 * a.ldx;
     const int srow = ltid >> 5, scol = (ltid & 31) * 8;
     f16x8 xg[NJ], xu[NJ];
-    bool xok[NJ];
+    uint32_t rowoff[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) rowoff[j] = (uint32_t)(min(srow + RSTEP * j, mrows - 1) * (int)a.ldx * 2);
     auto stage_load = [&](int chunk) {
-        const int kk = k0 + chunk * KC + scol;
-        const bool kok = kk < k1;
-        const int kc = kok ? kk : 0;
+        const int kc = min(k0 + chunk * KC + scol, a.K - 8);
+        const char* xb = reinterpret_cast<const char*>(xbase);
+        PIN_SGPR(xb);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int row = srow + RSTEP * j;
-            const f16* xr = xbase + (int64_t)min(row, mrows - 1) * a.ldx;
             f16x8 v, u;
             if (!PERM) {
-                v = ld16<f16x8>(xr + kc);
-                if (ACT == 1) u = ld16<f16x8>(xr + a.K + kc);
+                const uint32_t off = rowoff[j] + (uint32_t)kc * 2;
+                v = *(const GLOBAL_AS f16x8*)(xb + off);
+                if (ACT == 1) u = *(const GLOBAL_AS f16x8*)(xb + (int64_t)a.K * 2 + off);
             } else {
+                const GLOBAL_AS f16* xr = (const GLOBAL_AS f16*)(xb + rowoff[j]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     int ksrc = a.perm[kc + e];
@@ -215,17 +244,15 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
                     if (ACT == 1) u[e] = xr[a.K + ksrc];
                 }
             }
-            xg[j] = v;  // out-of-range rows / columns are zeroed at store time (keeps the loads in flight)
+            xg[j] = v;
             if (ACT == 1) xu[j] = u;
-            xok[j] = kok && row < mrows;
         }
     };
     auto stage_store = [&](int buf) {
         f16* dst = xs + buf * (32 * RS) + srow * RS + scol;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-            f16x8 t = xok[j] ? xg[j] : zero;
+            f16x8 t = xg[j];
             if (ACT == 1) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -235,7 +262,7 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
                     t[e] = (f16)((float)(f16)sl * (float)xu[j][e]);
                 }
             }
-            st16(dst + j * RSTEP * RS, t);
+            if (NJ * RSTEP == 32 || srow + RSTEP * j < 32) st16(dst + j * RSTEP * RS, t);
         }
     };
 
@@ -248,19 +275,41 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
     for (int i = 0; i < 2; ++i) accs[i] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int xoff = (lane & 31) * RS + (lane >> 5) * 32;
 
+    TRACE(1);
+    // Per-k-part arrival counters (monotonic): only the TN waves that share an x buffer synchronise per chunk.  A
+    // block-wide s_barrier would park every wave until the slowest of all TN*WK has finished its chunk (the SIMD
+    // arbiter serves its oldest wave first, so a third of the loop time went to that skew).
+    typedef __attribute__((address_space(3))) int lds_int;  // explicit LDS pointer: a generic one costs vmcnt(0) waits
+    volatile lds_int* sync_cnt = (volatile lds_int*)(smem + (size_t)WK * 2 * 32 * RS * sizeof(f16)) + wk;
+    if (wn == 0 && lane == 0) *sync_cnt = 0;
+    // Issue order matters: a wave's loads return in order, so the (L2-resident) first x chunk goes out before the
+    // HBM weight stream it would otherwise queue behind; then the small scale loads, then the ring of weights.
     stage_load(0);
+    u32x4 wq[RING];
+    uint32_t szr[RING];
+#pragma unroll
+    for (int s = 0; s < RING; ++s)
+        if (GROUP64) szr[s] = sz_at(s);
+#pragma unroll
+    for (int s = 0; s < RING; ++s) wq[s] = w_at(s);
     stage_store(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    TRACE(2);
 
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    // One chunk = 4 k64-steps.  All but the last chunk prefetch: next chunk's x into registers, next chunk's
+    // scales, and each weight slot is refilled in place right after it is consumed.  The last chunk is a separate
+    // instantiation without any of that (no wasted re-reads, no sync).
+    auto chunk_body = [&](const int chunk, auto last_tag) {
+        constexpr bool STAGE = !decltype(last_tag)::value, REFILL = STAGE;
+        constexpr int SB = 0;
 #ifndef ABL_NOSTAGE
-        stage_load(min(chunk + 1, nchunks - 1));  // last iteration restages its own chunk (unused)
+        if (STAGE) stage_load(chunk + 1);
 #endif
         // next chunk's scales: issued before this chunk's weight refills so that the loop-carried copy at the
-        // bottom only needs vmcnt(#weight loads) and the weight stream stays in flight across the barrier
-        uint32_t szn[RING];
-        if (GROUP64) {
+        // bottom only needs vmcnt(#weight loads) and the weight stream stays in flight across the sync
+        uint32_t szn[4];
+        if (GROUP64 && REFILL) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) szn[s4] = sz_at(chunk * 4 + s4 + RING);
         }
@@ -269,11 +318,11 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const int step = chunk * 4 + s4;
-            const u32x4 cur = wq[s4];
+            const u32x4 cur = wq[SB + s4];
             const f16* xk = xbuf + s4 * 64;
             f16x8 b[4];
             if (GROUP64) {
-                const f16x2 szh = __builtin_bit_cast(f16x2, szr[s4]);
+                const f16x2 szh = __builtin_bit_cast(f16x2, szr[SB + s4]);
                 const f16 zc1 = szh[1];
                 const f16 zd1 = (f16)960.f - zc1;  // -(64 + z + 1), exact
                 const f16x2 zc = {zc1, zc1}, zd = {zd1, zd1}, sc = {szh[0], szh[0]};
@@ -287,18 +336,21 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    int k = (min(ks0 + step, ks_last) * 8 + (lane >> 5) * 4 + i) * 8;
+                    int kreal = ((ks0 + step) * 8 + (lane >> 5) * 4 + i) * 8;
+                    int k = min(kreal, a.K - 8);
                     int g = min(k / a.gs, a.G - 1);
-                    f16x2 szh = __builtin_bit_cast(f16x2, szp[g * 32]);
+                    f16x2 szh = __builtin_bit_cast(f16x2, kreal < k1 ? szp[g * 32] : 0u);
                     f16 zc1 = szh[1], zd1 = (f16)960.f - zc1;
                     f16x2 zc = {zc1, zc1}, zd = {zd1, zd1}, sc = {szh[0], szh[0]};
                     b[i] = dequant8(cur[i], zc, zd, sc, EXr, M0r, M1r);
                 }
             }
-            // slot s4 is consumed: refill it in place for the next chunk (no register copy at the back-edge)
-            __builtin_amdgcn_sched_barrier(0);
-            wq[s4] = w_at(step + RING);
-            __builtin_amdgcn_sched_barrier(0);
+            if (REFILL) {
+                // the slot is consumed: refill it in place, RC chunks ahead (no register copy at the back-edge)
+                __builtin_amdgcn_sched_barrier(0);
+                wq[SB + s4] = w_at(step + RING);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #if defined(ABL_NOMFMA)
@@ -311,16 +363,27 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
 #endif
             }
         }
+        if (GROUP64 && REFILL) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) szr[SB + s4] = szn[s4];
+        }
+        if (!STAGE) return;
 #ifndef ABL_NOSTAGE
         stage_store((chunk + 1) & 1);
 #endif
-        if (GROUP64) {
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) szr[s4] = szn[s4];
-        }
+        TRACE(3 + 2 * min(chunk, 3));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
+        if (lane == 0) __hip_atomic_fetch_add((lds_int*)sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int target = TN * (chunk + 1);
+        while (__builtin_amdgcn_readfirstlane(*sync_cnt) < target) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        TRACE(4 + 2 * min(chunk, 3));
+    };
+    for (int chunk = 0; chunk + 1 < nchunks; ++chunk) chunk_body(chunk, std::false_type{});
+    chunk_body(nchunks - 1, std::true_type{});
+    TRACE(9);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every k-part is done with its x buffers: the reduction below reuses them
 
     f32x16 acc = accs[0] + accs[1];
     // ---- sum the WK k-parts through LDS (fixed order => deterministic) --------------------------------
@@ -334,6 +397,7 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        TRACE(11);
         if (wk > 0) return;
 #pragma unroll
         for (int k2 = 1; k2 < WK; ++k2) {
@@ -350,6 +414,7 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
     }
 
     // ---- epilogue: lane holds out[m = (r&3)+8(r>>2)+4(lane>>5)][n = nt*32 + (lane&31)] ------------
+    TRACE(12);
     if (nt_raw >= a.NT) return;
     const int n = nt * 32 + (lane & 31);
     if (ACT == 2) {
@@ -451,22 +516,33 @@ struct GemmPlan {
 static GemmPlan plan_gemm(int64_t K, int64_t N, int act = 0) {
     if (const char* ov = getenv("TGIS_GPTQ_PLAN")) {  // tuning hook: "KR,S,WK,TN"
         int kr = 0, sp = 0, wk = 0, tn = 0;
-        if (sscanf(ov, "%d,%d,%d,%d", &kr, &sp, &wk, &tn) == 4 && kr > 0 && (wk == 1 || wk == 2 || wk == 4) &&
-            (tn == 2 || tn == 4) && !(tn == 2 && wk == 1) && kr % (KC * wk) == 0 && (int64_t)sp * kr >= K &&
+        if (sscanf(ov, "%d,%d,%d,%d", &kr, &sp, &wk, &tn) == 4 && kr > 0 && (wk == 2 || wk == 4) &&
+            (tn >= 2 && tn <= 4) && kr % (KC * wk) == 0 && (int64_t)sp * kr >= K &&
             (int64_t)(sp - 1) * kr < K && (act != 2 || sp == 1))
             return {kr, sp, wk, tn};
     }
     const int64_t tiles = cdiv64(N, 32);
     const int64_t kchunks = cdiv64(K, KC);
-    int TN = tiles >= 512 ? 4 : 2;  // measured: wide N is best with 128-column blocks, narrow N with 64
-    int64_t colblocks = cdiv64(tiles, TN);
+    // Rules from the MI355X sweeps in profiles/r01_gemm_pmc.md (tools/sweep_gptq.py), M = 32:
+    //  wide N (or the SiLU epilogue, which needs the whole sum in one block): no global split, 96-column blocks of
+    //    12 waves while they fit one per CU (gate_up 4096x22016: 230 blocks, 17.3 us vs 19.2 for 128-column blocks);
+    //  medium N: 128-column blocks of two k-parts, split K until ~224 blocks (qkv 4096x12288: 10.8 vs 12.6 us);
+    //  narrow N: 64-column blocks of four k-parts, split K until 256 blocks.
+    int TN, WK;
     int64_t S = 1;
-    if (act != 2 && colblocks < 224) {  // the SiLU epilogue needs the complete sum in one block
-        S = std::max<int64_t>(1, std::min<int64_t>(kchunks, (256 + colblocks / 2) / colblocks));
+    if (act == 2 || tiles >= 512) {
+        TN = cdiv64(tiles, 3) <= 256 ? 3 : 4;
+        WK = 4;
+    } else {
+        TN = tiles >= 256 ? 4 : 2;
+        const int64_t colblocks = cdiv64(tiles, TN);
+        const int64_t want = TN == 4 ? 224 : 256;
+        S = std::max<int64_t>(1, std::min<int64_t>(kchunks, (want + colblocks / 2) / colblocks));
         while (S > 1 && (S - 1) * cdiv64(kchunks, S) >= kchunks) --S;  // no empty last split
+        WK = TN == 4 ? 2 : (cdiv64(kchunks, S) >= 4 ? 4 : 2);
     }
     int64_t KRc = cdiv64(kchunks, S);
-    int WK = KRc >= 4 ? 4 : 2;
+    if (KRc < WK) WK = 2;
     KRc = cdiv64(KRc, WK) * WK;  // whole chunks per k-part (rows beyond K contribute zeros)
     while (S > 1 && (S - 1) * KRc >= kchunks) --S;
     return {(int)(KRc * KC), (int)S, WK, TN};
@@ -532,13 +608,26 @@ extern "C" int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t 
     return 4096 + slab_bytes(M, N, pl.S);
 }
 
+template <int TN, int WK, int ACT, bool G64, bool PERM>
+static int launch_variant(dim3 grid, size_t lds, hipStream_t st, const GemmArgs& a) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_gemm_kernel<TN, WK, ACT, G64, PERM>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * RS * 2 + 64));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gptq_gemm_kernel<TN, WK, ACT, G64, PERM>), grid, dim3(64 * TN * WK), lds, st, a);
+    return TGIS_OK;
+}
+
 static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const void* bias, const int32_t* perm,
                        void* out, int64_t ldo, int64_t M, int64_t K, int64_t N, int64_t groups, int act, float* slabs,
                        int partial, const GemmPlan& pl, hipStream_t st) {
     PrepLayout p = prep_layout(K, N, groups);
     const int64_t mslabs = cdiv64(M, 32);
     const int64_t gs = K / groups;
-    const bool group64 = (gs % 64 == 0) || groups == 1;
+    const int64_t spg = gs / 64;  // k64-steps per group
+    const bool group64 = groups == 1 || (gs % 64 == 0 && (spg & (spg - 1)) == 0);
     GemmArgs a;
     a.x = (const f16*)x;
     a.ldx = ldx;
@@ -559,21 +648,15 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
     a.KS = (int)p.KS;
     a.slabs = slabs;
     a.partial = partial;
-    {
-        const char* d = getenv("TGIS_GPTQ_DBG");
-        a.dbg = d ? atoi(d) : 0;
-    }
+    a.spg_shift = 30;
+    if (groups > 1 && group64)
+        for (a.spg_shift = 0; (1 << a.spg_shift) < spg; ++a.spg_shift) {}
     dim3 grid((unsigned)cdiv64(p.NT, pl.TN), (unsigned)pl.S, (unsigned)mslabs);
-    const size_t lds = (size_t)pl.WK * 2 * 32 * RS * sizeof(f16);
-#define TGIS_LAUNCH_GEMM(T, W, A, G, P)                                                                       \
-    do {                                                                                                      \
-        static bool attr_done = false;                                                                        \
-        if (!attr_done) {                                                                                     \
-            TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_gemm_kernel<T, W, A, G, P>,                  \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * RS * 2)); \
-            attr_done = true;                                                                                 \
-        }                                                                                                     \
-        hipLaunchKernelGGL((gptq_gemm_kernel<T, W, A, G, P>), grid, dim3(64 * T * W), lds, st, a);            \
+    const size_t lds = (size_t)pl.WK * 2 * 32 * RS * sizeof(f16) + 64;  // x buffers + arrival counters
+#define TGIS_LAUNCH_GEMM(T, W, A, G, P)                                                        \
+    do {                                                                                       \
+        int rc_ = launch_variant<T, W, A, G, P>(grid, lds, st, a);                        \
+        if (rc_ != TGIS_OK) return rc_;                                                        \
     } while (0)
 #define TGIS_LAUNCH_GEMM_W(A, G, P)                      \
     do {                                                 \
@@ -582,8 +665,10 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
             TGIS_LAUNCH_GEMM(4, 4, A, G, P);             \
         else if (tw == 42)                               \
             TGIS_LAUNCH_GEMM(4, 2, A, G, P);             \
-        else if (tw == 41)                               \
-            TGIS_LAUNCH_GEMM(4, 1, A, G, P);             \
+        else if (tw == 34)                               \
+            TGIS_LAUNCH_GEMM(3, 4, A, G, P);             \
+        else if (tw == 32)                               \
+            TGIS_LAUNCH_GEMM(3, 2, A, G, P);             \
         else if (tw == 24)                               \
             TGIS_LAUNCH_GEMM(2, 4, A, G, P);             \
         else                                             \
@@ -670,17 +755,25 @@ extern "C" int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void
 }
 
 // debug aid (not part of the documented ABI): resident blocks per CU the runtime reports for the main kernel
+#ifdef TGIS_TRACE
+extern "C" int tgis_debug_set_trace(void* ptr) {
+    long long* p = (long long*)ptr;
+    TGIS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)));
+    return TGIS_OK;
+}
+#endif
+
 extern "C" int tgis_debug_gemm_occupancy(int tn, int wk) {
     int nb = -1;
-    const size_t lds = (size_t)wk * 2 * 32 * RS * sizeof(f16);
+    const size_t lds = (size_t)wk * 2 * 32 * RS * sizeof(f16) + 64;
     if (tn == 4 && wk == 4)
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<4, 4, 0, true, false>, 1024, lds);
     else if (tn == 2 && wk == 4)
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<2, 4, 0, true, false>, 512, lds);
     else if (tn == 2 && wk == 2)
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<2, 2, 0, true, false>, 256, lds);
-    else
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<4, 1, 0, true, false>, 256, lds);
+    else if (tn == 3 && wk == 4)
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<3, 4, 0, true, false>, 768, lds);
     return nb;
 }
 

@@ -1,0 +1,85 @@
+"""In-kernel timeline of the GPTQ GEMM (debug build with -DTGIS_TRACE): per-wave s_memtime stamps.
+
+    python tools/trace_gemm.py K N [act] [plan]      (on the GPU box; builds lib/trace.so with hipcc first)
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pkg = os.path.join(root, "text-generation-inference_amd")
+lib = os.path.join(pkg, "lib", "trace.so")
+if not os.path.exists(lib) or os.environ.get("TRACE_REBUILD"):
+    srcs = [os.path.join(pkg, "csrc", f) for f in sorted(os.listdir(os.path.join(pkg, "csrc"))) if f.endswith(".hip")]
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DTGIS_TRACE",
+                           "-o", lib] + srcs)
+os.environ["TGIS_HIP_LIB"] = lib
+sys.path.insert(0, pkg)
+import torch  # noqa: E402
+from tgis_amd import native as nat  # noqa: E402
+
+K, N = int(sys.argv[1]), int(sys.argv[2])
+act = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if len(sys.argv) > 4:
+    os.environ["TGIS_GPTQ_PLAN"] = sys.argv[4]
+dev = torch.device("cuda:0")
+gs, M = 128, 32
+G = K // gs
+sets = []
+for i in range(4):
+    qw = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=dev)
+    qz = torch.randint(-2**31, 2**31 - 1, (G, N // 8), dtype=torch.int32, device=dev)
+    sc = (torch.rand(G, N, device=dev) * 0.002 + 0.001).half()
+    sets.append(nat.GptqWeight(qw, qz, sc, None, 4, gs, gate_up=(act == 2)))
+x = torch.randn(M, K, device=dev).half()
+ws = nat.Workspace(sets[0].workspace_bytes(M), dev)
+NB = 4096
+trace = torch.zeros(NB * 16 * 32, dtype=torch.int64, device=dev)
+L = nat.load_library()
+L.tgis_debug_set_trace.argtypes = [ctypes.c_void_p]
+
+
+def run(i):
+    return nat.gptq_gemm(x, sets[i], ws, act=act)
+
+
+for i in range(3):
+    run(i)
+torch.cuda.synchronize()
+assert L.tgis_debug_set_trace(ctypes.c_void_p(trace.data_ptr())) == 0
+trace.zero_()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+run(3)
+e1.record()
+torch.cuda.synchronize()
+print(f"K={K} N={N} act={act}: event time {e0.elapsed_time(e1) * 1e3:.1f} us")
+t = trace.view(NB, 16, 32).cpu()
+used = t[:, :, 0] != 0
+t0 = t[:, :, 0][used].min().item()
+names = {0: "entry", 1: "weights issued", 2: "x0 staged+barrier", 3: "chunk0 done", 4: "chunk0 barrier", 5: "chunk1 done",
+         6: "chunk1 barrier", 7: "chunk2 done", 8: "chunk2 barrier", 9: "last chunk done", 10: "last barrier",
+         11: "reduce barrier", 12: "epilogue start"}
+print(f"blocks used: {int(used.any(dim=1).sum())}, waves: {int(used.sum())}   (ticks of s_memtime, relative to first entry)")
+for i in range(13):
+    v = t[:, :, i]
+    m = v != 0
+    if not m.any():
+        continue
+    r = (v[m] - t0).float()
+    q = torch.quantile(r, torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0]))
+    print(f"  {i:2d} {names[i]:20s} n={int(m.sum()):6d}  min={q[0]:8.0f} p10={q[1]:8.0f} p50={q[2]:8.0f} p90={q[3]:8.0f} max={q[4]:8.0f}")
+# per-wave durations
+for i in range(4):
+    names[16 + 4 * i] = f"c1 step{i} top"
+    names[17 + 4 * i] = f"c1 step{i} dequant done"
+    names[18 + 4 * i] = f"c1 step{i} mfma issued"
+names[9] = "last chunk done"
+pairs = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (6, 9), (4, 9), (2, 9), (9, 11), (11, 12), (0, 12)]
+for a_, b_ in pairs:
+    va, vb = t[:, :, a_], t[:, :, b_]
+    m = (va != 0) & (vb != 0)
+    if m.any():
+        d = (vb[m] - va[m]).float()
+        print(f"  dt {names[a_]:>24s} -> {names[b_]:24s} p50={d.median():8.0f} p90={torch.quantile(d, 0.9):8.0f} max={d.max():8.0f}")
