@@ -14,6 +14,7 @@ Rank 0 prints ONE JSON line with the contract fields plus "roofline" (dominant k
 algorithmic KV bytes / HIP-event launch duration) and "cpu_baseline" (fp32 CPU oracle on a bounded sample).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -118,6 +119,22 @@ def cpu_baseline(cfg, quantize, B, ctx, groupsize=128):
             "ms_per_step": round(step_s * 1e3, 1),
             "sample": f"one decoder layer of one decode step at B={B}, ctx={ctx}, fp32, {reps} repetitions, "
                       f"x{cfg.num_hidden_layers} layers + lm_head/greedy"}
+
+
+def pmc_traffic(config, B, ctx_mean):
+    """HBM bytes per attention launch from the committed rocprofv3 counter passes (tools/profile_round.sh: FETCH_SIZE
+    and WRITE_SIZE in separate --pmc runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for 16 B/lane streaming reads on gfx950).  Counters cannot be collected inside the timed run, so the figure is read
+    from profiles/ and only reported for the workload it was measured on; otherwise null."""
+    if (config, B, ctx_mean) != ("llama2-7b-gptq", 32, 1024):
+        return None
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_attn_traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    if d.get("fetch_bytes_per_launch_corrected") is None:
+        return None
+    return int(d["fetch_bytes_per_launch_corrected"] + (d.get("write_bytes_per_launch_uncalibrated") or 0))
 
 
 def main():
@@ -226,7 +243,8 @@ def main():
             achieved = bytes_per_launch / avg_s / 1e9
             roofline = {"bound": "hbm", "kernel": "attn_paged_kernel (decode)", "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": None, "launches": int(n_attn), "avg_launch_us": round(avg_s * 1e6, 2),
+                        "traffic": pmc_traffic(args.config, B, ctx_mean), "launches": int(n_attn),
+                        "avg_launch_us": round(avg_s * 1e6, 2),
                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
                         "gemm_launches": int(n_gemm), "gemm_avg_launch_us": round(ms_gemm * 1e3 / max(n_gemm, 1), 2)}
 
