@@ -292,9 +292,18 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
         if (GROUP64) szr[s] = sz_at(s);
 #pragma unroll
     for (int s = 0; s < RING; ++s) wq[s] = w_at(s);
-    stage_store(0);
+    // the only block-wide barrier before the reduction publishes the zeroed counters; it does not wait for the loads
+    // above, and from here on each k-part group paces itself
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    auto group_sync = [&](int target) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add((lds_int*)sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__builtin_amdgcn_readfirstlane(*sync_cnt) < target) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    stage_store(0);
+    group_sync(TN);
     TRACE(2);
 
     // One chunk = 4 k64-steps.  All but the last chunk prefetch: next chunk's x into registers, next chunk's
@@ -372,11 +381,7 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
         stage_store((chunk + 1) & 1);
 #endif
         TRACE(3 + 2 * min(chunk, 3));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add((lds_int*)sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int target = TN * (chunk + 1);
-        while (__builtin_amdgcn_readfirstlane(*sync_cnt) < target) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
+        group_sync(TN * (chunk + 2));
         TRACE(4 + 2 * min(chunk, 3));
     };
     for (int chunk = 0; chunk + 1 < nchunks; ++chunk) chunk_body(chunk, std::false_type{});
