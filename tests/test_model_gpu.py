@@ -282,3 +282,44 @@ def test_grpc_shard_end_to_end(gpu_device):
         check_ids([t.token_id for t in res.output_tokens], want, f"grpc step {i}")
         assert res.forward_time_ns > 0 and not res.errors
     assert lm.kv_cache.free_pages == lm.kv_cache.num_pages
+
+
+def test_prompt_prefix_equals_the_same_tokens_in_the_prompt(gpu_device, tmp_path):
+    """§8(f) row 4 on the product path: a soft prompt whose rows are the embeddings of tokens [a, b, c] must generate
+    exactly what the prompt "[a, b, c] + text" generates (same positions, same KV) — prefill and decode steps."""
+    from tgis_amd.prompt_cache import PrefixCache
+
+    meta, _ = load_fixture("llama_dense_ragged")
+    cfg = _cfg(meta)
+    tensors = tiny_llama_tensors(cfg, seed=meta["seed"], quantize=None, groupsize=meta["groupsize"])
+    lm, tok = _build(cfg, tensors, None, meta["groupsize"], torch.float16, use_graphs=True)
+    prompts = meta["prompts"][:3]
+    head = [7, 19, 23]
+    (tmp_path / "soft").mkdir()
+    torch.save(tensors["model.embed_tokens.weight"][head].float().cpu(), tmp_path / "soft" / "decoder.pt")
+    cache = PrefixCache(lm.device, lm.dtype, max_length=16, hidden_size=cfg.hidden_size, store=tmp_path, budget_mb=8)
+
+    def run(pb, prefix_cache):
+        with lm.context_manager():
+            batch, errs = lm.batch_type.from_pb(pb, tok, lm.dtype, lm.device, lm.word_embeddings, prefix_cache, True)
+        assert not errs
+        tap, ids, logits = _LogitTap(lm), [], []
+        for i in range(5):
+            toks, lg = _step(lm, batch, tap, first=(i == 0))
+            ids.append([t.token_id for t in toks])
+            logits.append(lg)
+        lens = list(batch.input_lengths)
+        batch.release()
+        return ids, logits, lens
+
+    pb_tokens = _pb([head + list(p) for p in prompts], 8)
+    pb_prefix = _pb(prompts, 8)
+    for r in pb_prefix.requests:
+        r.prefix_id = "soft"
+    ids_t, logits_t, lens_t = run(pb_tokens, None)
+    ids_p, logits_p, lens_p = run(pb_prefix, cache)
+    assert lens_t == lens_p, "input lengths include the prefix"
+    assert ids_t == ids_p
+    for a, b in zip(logits_t, logits_p):
+        np.testing.assert_allclose(a, b, atol=1e-3)
+    assert lm.kv_cache.free_pages == lm.kv_cache.num_pages

@@ -11,6 +11,7 @@ import torch
 
 from tgis_amd.models.types import Batch, GenerateError
 from tgis_amd.pb import generate_pb2
+from tgis_amd.prompt_cache import PrefixCache, max_prompt_prefix_length, prefix_store_path
 from tgis_amd.utils.token_types import InputTokens, TokenInfo
 
 B = TypeVar("B", bound=Batch)
@@ -31,8 +32,21 @@ class Model(ABC):
             self.word_embeddings = self.model.get_input_embeddings()
         except Exception:
             self.word_embeddings = None
-        # prompt-prefix (soft prompt) cache: SURVEY.md §8(f) row 4, not built yet
+        # prompt-prefix (soft prompt) cache, enabled by $PREFIX_STORE_PATH (models/model.py:56-95 of the reference)
         self.prefix_cache = None
+        if prefix_store_path() is not None and self.word_embeddings is not None:
+            if max_seq_length is None:
+                raise ValueError("max_seq_length must be set when a prompt prefix store is configured")
+            from tgis_amd.utils.layers import TensorParallelEmbedding
+            return_zero = False
+            # an embedding that leaves the all-reduce to its caller holds partial rows on every rank: only rank 0 may
+            # add the real prefix, the others add zeros (model.py:76-82)
+            if isinstance(self.word_embeddings, TensorParallelEmbedding) and not self.word_embeddings.reduce:
+                return_zero = self.word_embeddings.process_group.rank() != 0
+            self.prefix_cache = PrefixCache(
+                device=self.device, dtype=dtype, max_length=max_prompt_prefix_length(max_seq_length),
+                hidden_size=getattr(self.config, "hidden_size", None) or getattr(self.config, "n_embd", None),
+                return_zero=return_zero)
         self.context_manager = torch.inference_mode
 
     @property
