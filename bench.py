@@ -215,6 +215,7 @@ def main():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
         ctx_timed_mean = L_in + 1 + W + (K - 1) / 2.0  # keys attended per step, averaged over the timed steps
+        graphs_kept = bool(lm.use_graphs)  # false if a capture with collectives fell back to eager launches
 
         roofline = None
         if not args.no_roofline:  # every rank runs it (the forward contains collectives when tp > 1)
@@ -260,7 +261,8 @@ def main():
         "config": {"workload": f"{args.config} decode, B={B}, mean ctx {ctx_timed_mean:.1f} "
                                f"(L_in={L_in}, {W} warm-up + {K} timed steps), greedy",
                    "global_batch": B, "seq_len": int(round(ctx_timed_mean)), "parallelism": f"tp{tp}",
-                   "weights": "int4 GPTQ g128" if quantize == "gptq" else dtype_s, "hip_graph": graphs_used},
+                   "weights": "int4 GPTQ g128" if quantize == "gptq" else dtype_s,
+                   "hip_graph": graphs_used and graphs_kept},
         "step_roofline": {"algorithmic_bytes_per_step": int(ab["total"]), "ms_at_hbm_peak": round(step_roof_ms, 4),
                           "frac_of_hbm_peak": round(step_roof_ms / (elapsed / K * 1e3), 4)},
     }

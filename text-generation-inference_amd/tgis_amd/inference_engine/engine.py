@@ -23,7 +23,8 @@ class BaseInferenceEngine:
         self.world_size = int(os.getenv("WORLD_SIZE", "1"))
         if torch.cuda.is_available():
             gpu_count = torch.cuda.device_count()
-            assert self.world_size <= gpu_count, \
+            # TGIS_ALLOW_SHARED_GPU=1: several ranks on one device (TP tests on a single-GPU box, gloo collectives)
+            assert self.world_size <= gpu_count or os.getenv("TGIS_ALLOW_SHARED_GPU") == "1", \
                 f"{self.world_size} shards configured but only {gpu_count} GPUs detected"
             device_index = self.rank % gpu_count
             torch.cuda.set_device(device_index)

@@ -300,11 +300,21 @@ class _DecodeGraph:
         if not self.lm.use_graphs:
             return self._step()
         if self.graph is None:
-            self._step()  # warm-up: sizes the workspaces, builds rope tables outside the capture
+            # warm-up: sizes the workspaces, builds rope tables and (tp > 1) initialises the RCCL communicators outside
+            # the capture
+            self._step()
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.logits, self.ids, self.logprobs = self._step()
+            try:
+                with torch.cuda.graph(g):
+                    self.logits, self.ids, self.logprobs = self._step()
+            except Exception as e:  # every rank runs the same code, so every rank falls back together
+                if self.lm.tp_world == 1:
+                    raise
+                logging.warning("HIP graph capture with collectives failed (%s): decode steps run eagerly", e)
+                self.lm.use_graphs = False
+                torch.cuda.synchronize()
+                return self._step()
             self.graph = g
         self.graph.replay()
         return self.logits, self.ids, self.logprobs
@@ -348,9 +358,14 @@ class FlashCausalLM(Model):
             kv_cache_pages = self._default_kv_pages()
         self.kv_cache = PagedKVCache(self.num_layers, self.num_kv_heads, self.head_size, kv_cache_pages, dtype,
                                      self.device)
-        # graphs with RCCL collectives inside are opt-in until exercised on a multi-GPU node
+        # tp > 1: the captured step contains the RCCL all-reduces / all-gather (capturable on ROCm like NCCL on CUDA);
+        # a failed capture falls back to eager launches (_DecodeGraph.run), TGIS_TP_GRAPHS=false skips the attempt, and
+        # host-mediated gloo collectives (single-GPU TP tests) cannot be captured at all
         tp = engine.world_size if hasattr(engine, "world_size") else 1
-        self.use_graphs = USE_GRAPHS and (tp == 1 or os.getenv("TGIS_TP_GRAPHS", "false").lower() in ("1", "true"))
+        self.tp_world = tp
+        tp_graphs = os.getenv("TGIS_TP_GRAPHS", "true").lower() in ("1", "true") and \
+            os.getenv("TGIS_DIST_BACKEND", "nccl") != "gloo"
+        self.use_graphs = USE_GRAPHS and (tp == 1 or tp_graphs)
         self._graphs = {}
 
     def _default_kv_pages(self) -> int:

@@ -57,7 +57,8 @@ def initialize_torch_distributed(world_size: int, rank: int):
     if world_size == 1 or os.getenv("DEBUG", None) == "1":
         return FakeGroup(rank, world_size)
     if not torch.distributed.is_initialized():
-        if torch.cuda.is_available():
+        # TGIS_DIST_BACKEND=gloo: host-mediated collectives on GPU tensors, for TP tests on a single-GPU box
+        if torch.cuda.is_available() and os.getenv("TGIS_DIST_BACKEND", "nccl") != "gloo":
             from torch.distributed import ProcessGroupNCCL
 
             backend = "nccl"  # RCCL on ROCm

@@ -168,12 +168,13 @@ class TensorParallelHead(SuperLayer):
         if not self.should_gather:
             return local
         world = self.process_group.size()
-        # gather [V/tp, T] blocks so the result is a plain transpose view (layers.py:244-269)
+        # gather [V/tp, T] blocks (layers.py:244-269), then hand out row-major [T, V]: the fused argmax/logprob
+        # kernel and the warpers read contiguous rows
         gather_in = local.t().contiguous()
         world_out = torch.empty((gather_in.shape[0] * world, gather_in.shape[1]), dtype=local.dtype,
                                 device=local.device)
         torch.distributed.all_gather_into_tensor(world_out, gather_in, group=self.process_group)
-        return world_out.t()
+        return world_out.t().contiguous()
 
     __call__ = forward
 
