@@ -128,3 +128,30 @@ def test_weights_row_col_sharding_rules():
         assert torch.equal(qw, t["model.layers.0.mlp.down_proj.qweight"][rank * I // 16:(rank + 1) * I // 16])
     with pytest.raises(AssertionError):
         DictWeights({"a.weight": torch.zeros(7, 4)}, "cpu", torch.float16, FakeGroup(0, 2)).get_sharded("a.weight", 0)
+
+
+@pytest.mark.parametrize("K,gs,world", [(11008, 128, 4), (11008, 128, 8), (448, 64, 2), (512, 64, 2)])
+def test_row_parallel_gptq_regroups_misaligned_shards(K, gs, world):
+    """Row-parallel GPTQ shards whose rows do not end on group boundaries (llama-7B down_proj at tp=4/8) are served by
+    splitting groups into sub-groups with copied scale/zero rows: every rank's dequantised slice must equal the slice
+    of the unsharded dequantised matrix, bit for bit."""
+    from oracle import ops_ref
+    from tgis_amd.utils.dist import FakeGroup
+    from tgis_amd.utils.weights import DictWeights
+
+    N = 64
+    qw, qz, sc, gi = ops_ref.make_gptq_tensors(K, N, gs, seed=K + world)
+    full = ops_ref.gptq_dequant(qw, qz, sc, None, gs)
+    t = {"p.qweight": torch.from_numpy(qw), "p.qzeros": torch.from_numpy(qz), "p.scales": torch.from_numpy(sc),
+         "p.g_idx": torch.arange(K, dtype=torch.int32) // gs}
+    rows = K // world
+    for rank in range(world):
+        w = DictWeights(t, torch.device("cpu"), torch.float16, FakeGroup(rank, world))
+        w.gptq_bits, w.gptq_groupsize = 4, gs
+        lqw, lqz, lsc, lgi, bits, lgs, _ = w.get_multi_weights_row("p", "gptq")
+        assert lgi is None and lqw.shape[0] * 8 == rows and rows % lgs == 0 and lgs % 8 == 0
+        assert lqz.shape[0] == lsc.shape[0] == rows // lgs
+        if rows % gs == 0:
+            assert lgs == gs, "aligned shards keep the checkpoint's groups"
+        local = ops_ref.gptq_dequant(lqw.numpy(), lqz.numpy(), lsc.numpy(), None, lgs)
+        assert torch.equal(local, full[rank * rows:(rank + 1) * rows])

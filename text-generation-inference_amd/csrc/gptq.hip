@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
     const char* sztile = reinterpret_cast<const char*>(a.prep + a.offB) + (int64_t)nt * a.G * 128;
     const uint32_t woff = lane * 16, szoff = (lane & 31) * 4;
     // prefetches past this wave's rows re-read its own last step (a cache hit), not the next k-part's rows
-    const int ks_clamp = min(ks_last, max(ks0, (k1 >> 6) - 1));
+    const int ks_clamp = min(ks_last, max(ks0, ((k1 + 63) >> 6) - 1));  // K % 64 == 32: the last step is half valid
     const int ks_end = k1 >> 6;  // first step past this wave's rows: its scale is forced to zero (GROUP64: K % 64 == 0)
     auto sz_at = [&](int step) -> uint32_t {   // GROUP64: one {scale, zero} pair per lane and k64-step
         const int g = min((ks0 + step) >> a.spg_shift, a.G - 1);

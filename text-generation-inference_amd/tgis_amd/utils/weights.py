@@ -9,6 +9,7 @@ to its Triton kernel, weights.py:150-156; this build has no second kernel family
 
 `DictWeights` serves the same interface from an in-memory dict (synthetic benchmark weights and tests)."""
 import json
+import math
 import os
 from pathlib import Path
 from typing import Any, Dict, List, Optional, Tuple
@@ -96,7 +97,22 @@ class _Base:
                         "act-order GPTQ with row tensor parallelism needs the activation permutation across "
                         "ranks (the reference falls back to its Triton kernel here); not supported")
             qweight = self.get_sharded(f"{prefix}.qweight", dim=0)
-            if groupsize >= 0:
+            rows = qweight.shape[0] * (32 // bits)  # this rank's K
+            if groupsize >= 0 and tp > 1 and rows % groupsize != 0:
+                # The rank's rows do not start/end on group boundaries (llama-7B down_proj: 11008/4 = 2752 = 21.5
+                # groups of 128).  The reference can only serve this through its g_idx (Triton) kernel; here the
+                # groups are split into sub-groups of gcd(group, rows) rows that carry a copy of their parent's
+                # scale / zero-point, which is numerically identical and keeps the streaming kernel's layout.
+                sub = math.gcd(groupsize, rows)
+                if sub % 8 != 0:
+                    raise NotImplementedError(f"{prefix}: {rows} rows per rank cannot be regrouped from groups of "
+                                              f"{groupsize} (sub-group {sub} is not a multiple of 8)")
+                start = self.process_group.rank() * rows
+                parent = (start + torch.arange(rows // sub) * sub) // groupsize
+                qzeros = self.get_tensor(f"{prefix}.qzeros")[parent.to(self.device)].contiguous()
+                scales = self.get_tensor(f"{prefix}.scales")[parent.to(self.device)].contiguous()
+                groupsize = sub
+            elif groupsize >= 0:
                 qzeros = self.get_sharded(f"{prefix}.qzeros", dim=0)
                 scales = self.get_sharded(f"{prefix}.scales", dim=0)
             else:
