@@ -119,6 +119,12 @@ int64_t tgis_dense_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
 int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared, const void* bias, void* out,
                     int64_t ldo, int64_t M, int64_t K, int64_t N, int dtype, int out_f32, int act,
                     void* workspace, int64_t workspace_bytes, void* stream);
+/* Deferred split-K for M <= 32, as tgis_gptq_gemm_f16_partial: the fp32 partial sums [num_slabs][32][slab_ld] are
+ * left for the consumer kernel (tgis_rmsnorm_residual_partial / tgis_rope_kv_write_partial), which adds the bias. */
+int64_t tgis_dense_gemm_partial_bytes(int64_t K, int64_t N);
+int tgis_dense_gemm_partial(const void* x, int64_t ldx, const void* prepared, int64_t M, int64_t K, int64_t N,
+                            int dtype, int act, float* slabs, int64_t slabs_bytes, int* num_slabs,
+                            int64_t* slab_ld, void* stream);
 
 /* ---- fused residual-add + RMSNorm / LayerNorm (replaces dropout_layer_norm.dropout_add_ln_fwd,
  *      custom_modeling/flash_llama_modeling.py:132-152, utils/layers.py:376-396) ---------------- */

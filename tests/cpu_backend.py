@@ -142,5 +142,6 @@ def install(monkeypatch):
         argmax_logprob=_argmax_logprob, attn_num_splits=lambda *a: 1, attn_workspace_bytes=lambda *a: 0,
         act_mul=lambda gu, I, out=None: ops_ref.silu_mul(gu, I).to(gu.dtype),
         gptq_gemm_partial=lambda x, w, bias=None, act=0: _gptq_gemm(x, w, None, bias=bias, act=act),
+        dense_gemm_partial=lambda x, w, bias=None, act=0: _dense_gemm(x, w, None, bias=bias, act=act),
     ).items():
         monkeypatch.setattr(native, name, fn)

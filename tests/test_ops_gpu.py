@@ -359,3 +359,22 @@ def test_gptq_gemm_gate_up_epilogue(nat, gpu_device, M, K, I):
     _close(got, want, rtol=4e-3, atol=1.5e-3 * float(lin.float().abs().max()) + 1e-4, what="gate_up epilogue")
     wd = nat.gptq_dequant(w).float().cpu()
     assert torch.equal(wd, ops_ref.gptq_dequant(qw, qz, sc, gi, gs).half().float())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N", [(16, 2048, 2048), (32, 5632, 2048), (3, 256, 96)])
+def test_dense_partial_then_rmsnorm_is_bit_identical_to_unfused(nat, gpu_device, dtype, M, K, N):
+    g = torch.Generator().manual_seed(M + K)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(dtype)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(dtype).to(gpu_device)
+    res = torch.randn(M, N, generator=g).to(dtype).to(gpu_device)
+    bias = (torch.randn(N, generator=g) * 0.1).to(dtype).to(gpu_device)
+    wn = (1 + 0.1 * torch.randn(N, generator=g)).to(dtype).to(gpu_device)
+    dw = nat.DenseWeight(w.to(gpu_device))
+    ws = nat.Workspace(dw.workspace_bytes(M), gpu_device)
+    y0, r0 = nat.rmsnorm_residual(nat.dense_gemm(x, dw, ws, bias=bias), res, wn, 1e-5)
+    part = nat.dense_gemm_partial(x, dw, bias=bias)
+    if K >= 2048:
+        assert part.S > 1, "this shape is meant to exercise a real split"
+    y1, r1 = nat.rmsnorm_residual(part, res, wn, 1e-5)
+    assert torch.equal(y0, y1) and torch.equal(r0, r1)

@@ -6,6 +6,7 @@
 // wave load is one contiguous KiB:  [NT=ceil(N/32)][KS=ceil(K/64)][4][64 lanes][8 elems];
 // lane l, word i = W[n = nt*32 + (l&31)][k = (ks*8 + (l>>5)*4 + i)*8 .. +7].
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -39,226 +40,308 @@ __global__ void dense_prepare_kernel(const T* __restrict__ w, T* __restrict__ ou
 struct DenseArgs {
     const void* x;
     int64_t ldx;
-    const void* prep;
+    const uint8_t* prep;
     const void* bias;
     void* out;
     int64_t ldo;
-    int M, K, N, KB, S, NT, KS;
+    int M, K, N;   // M = all rows (grid.z walks 32-row slabs)
+    int KR;        // k-range per block (multiple of 256 * WK)
+    int S;         // global k splits
+    int NT, KS;
     int out_f32;
-    float* slabs;
+    float* slabs;  // [Mslabs][S][32][NT*32] f32 partial sums (S > 1 or partial mode)
+    int partial;   // 1: always leave fp32 slabs (deferred reduce), never write `out`
 };
 
-constexpr int DMAXSTEPS = 4;
-constexpr int DTHREADS = 512;
+constexpr int DKC = 256;      // k per LDS chunk (4 k64-steps)
+constexpr int DRS = DKC + 8;  // LDS row stride in elements (+16 B -> conflict-free ds_read_b128)
+constexpr int DRING = 2;      // k64-steps of weights in flight per wave (2 x 4 KiB)
+#define DENSE_GLOBAL_AS __attribute__((address_space(1)))
 
-template <typename T, int WN, int ACT>
-__global__ __launch_bounds__(DTHREADS) void dense_gemm_kernel(DenseArgs a) {
+// Same structure as gptq_gemm_kernel (gptq.hip) without the dequantisation: a block of TN*WK waves owns 32*TN columns
+// x KR rows; wave (tile wn, k-part wk) streams its tile's fragments over its own k-range (4 KiB per k64-step, two
+// steps in flight, refilled in place), each k-part group double-buffers 32x256 chunks of x through LDS and paces
+// itself with an LDS arrival counter; k-parts are summed through LDS in fixed order; global k-splits leave fp32
+// slabs for the consumer kernel.  The image is zero-padded past K and N; x columns past the wave's k-range are
+// zeroed when the chunk is staged (the fragments there belong to the next k-part).
+template <typename T, int TN, int WK, int ACT>
+__global__ __launch_bounds__(64 * TN * WK) void dense_gemm_kernel(DenseArgs a) {
     using V8 = typename VecT<T>::x8;
-    constexpr int WK = 8 / WN;
+    constexpr int GT = 64 * TN;
+    constexpr int NJ = (1024 + GT - 1) / GT;
+    constexpr int RSTEP = GT / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wn = w % WN, wk = w / WN;
-    const int ntg = blockIdx.x, split = blockIdx.y;
-    const int kb0 = split * a.KB;
-    const int kb1 = min(a.K, kb0 + a.KB);
-    const int steps_total = (kb1 - kb0 + 63) >> 6;
-    const int rs = a.KB + 8;
-    T* xs = reinterpret_cast<T*>(smem);
-    const T* x = reinterpret_cast<const T*>(a.x);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w % TN, wk = w / TN, ltid = wn * 64 + lane;
+    T* xs = reinterpret_cast<T*>(smem) + wk * (2 * 32 * DRS);
+    const int ntg = blockIdx.x, split = blockIdx.y, mslab = blockIdx.z;
+    const int m0 = mslab * 32;
+    const int mrows = min(32, a.M - m0);
+    const int krp = a.KR / WK;
+    const int k0 = split * a.KR + wk * krp;
+    const int k1 = min(a.K, k0 + krp);
+    const int nchunks = krp / DKC;
+    const int nt_raw = ntg * TN + wn;
+    const int nt = min(nt_raw, a.NT - 1);
+    const int ks0 = k0 >> 6;
+    const int ks_clamp = min(a.KS - 1, max(ks0, ((k1 + 63) >> 6) - 1));
 
-    const int spw = (steps_total + WK - 1) / WK;
-    const int st0 = wk * spw;
-    const int nt = ntg * WN + wn;
-    const int nsteps = (nt < a.NT) ? max(0, min(spw, steps_total - st0)) : 0;
-    const int ks0 = (kb0 >> 6) + st0;
-    V8 wv[DMAXSTEPS][4];
-    const V8* wbase = reinterpret_cast<const V8*>(a.prep) + ((int64_t)nt * a.KS + ks0) * 256 + lane;
+    const char* wtile = reinterpret_cast<const char*>(a.prep) + (int64_t)nt * a.KS * 4096;
+    const uint32_t woff = lane * 16;
+    V8 wq[DRING][4];
+    auto w_load = [&](int step, V8* dst) {
+        const char* p = wtile + (int64_t)min(ks0 + step, ks_clamp) * 4096;
+        asm volatile("" : "+s"(p));  // wave-uniform base in SGPRs: (sgpr base + lane offset) addressing
 #pragma unroll
-    for (int s = 0; s < DMAXSTEPS; ++s)
-        if (s < nsteps) {
+        for (int i = 0; i < 4; ++i)
+            dst[i] = __builtin_nontemporal_load((const DENSE_GLOBAL_AS V8*)(p + i * 1024 + woff));
+    };
+
+    // ---- x staging (as in gptq.hip): rows past M read a clamped row (their outputs are never stored); columns past
+    //      the k-range are zeroed at store time --------------------------------------------------------------------
+    const T* xbase = reinterpret_cast<const T*>(a.x) + (int64_t)m0 * a.ldx;
+    const int srow = ltid >> 5, scol = (ltid & 31) * 8;
+    V8 xg[NJ], xu[NJ];
+    bool xok;
+    uint32_t rowoff[NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wv[s][i] = __builtin_nontemporal_load(wbase + s * 256 + i * 64);
+    for (int j = 0; j < NJ; ++j) rowoff[j] = (uint32_t)(min(srow + RSTEP * j, mrows - 1) * (int)a.ldx * 2);
+    auto stage_load = [&](int chunk) {
+        const int kk = k0 + chunk * DKC + scol;
+        xok = kk < k1;
+        const int kc = min(kk, a.K - 8);
+        const char* xb = reinterpret_cast<const char*>(xbase);
+        asm volatile("" : "+s"(xb));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const uint32_t off = rowoff[j] + (uint32_t)kc * 2;
+            xg[j] = *(const DENSE_GLOBAL_AS V8*)(xb + off);
+            if (ACT == 1) xu[j] = *(const DENSE_GLOBAL_AS V8*)(xb + (int64_t)a.K * 2 + off);
         }
-
-    {
-        const int c8n = a.KB >> 3;
-        for (int idx = tid; idx < 32 * c8n; idx += DTHREADS) {
-            int row = idx / c8n, c8 = idx - row * c8n;
-            int k = kb0 + c8 * 8;
-            V8 v;
+    };
+    auto stage_store = [&](int buf) {
+        T* dst = xs + buf * (32 * DRS) + srow * DRS + scol;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (T)0.f;
-            if (row < a.M && k < kb1) {
-                const T* xr = x + (int64_t)row * a.ldx;
-                if (k + 8 <= kb1) {
-                    v = ld16<V8>(xr + k);
-                    if (ACT == 1) {
-                        V8 u = ld16<V8>(xr + a.K + k);
+        for (int j = 0; j < NJ; ++j) {
+            V8 t = xg[j];
+            if (ACT == 1) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            float g = to_f32(v[e]);
-                            float sl = g / (1.f + __expf(-g));
-                            v[e] = from_f32<T>(to_f32(from_f32<T>(sl)) * to_f32(u[e]));
-                        }
-                    }
-                } else {
-                    for (int e = 0; e < 8; ++e)
-                        if (k + e < kb1) {
-                            float g = to_f32(xr[k + e]);
-                            if (ACT == 1) {
-                                float sl = g / (1.f + __expf(-g));
-                                g = to_f32(from_f32<T>(sl)) * to_f32(xr[a.K + k + e]);
-                            }
-                            v[e] = from_f32<T>(g);
-                        }
+                for (int e = 0; e < 8; ++e) {
+                    float g = to_f32(t[e]);
+                    float sl = g / (1.f + __expf(-g));
+                    // reference rounds silu(gate) to the model dtype before the multiply (eager torch ops)
+                    t[e] = from_f32<T>(to_f32(from_f32<T>(sl)) * to_f32(xu[j][e]));
                 }
             }
-            st16(xs + row * rs + c8 * 8, v);
-        }
-    }
-    __syncthreads();
-
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const T* xrow = xs + (lane & 31) * rs + (lane >> 5) * 32;
+            if (!xok) {
 #pragma unroll
-    for (int s = 0; s < DMAXSTEPS; ++s)
-        if (s < nsteps) {
-            const T* xk = xrow + (st0 + s) * 64;
+                for (int e = 0; e < 8; ++e) t[e] = (T)0.f;
+            }
+            if (NJ * RSTEP == 32 || srow + RSTEP * j < 32) st16(dst + j * RSTEP * DRS, t);
+        }
+    };
+
+    f32x16 accs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) accs[i] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int xoff = (lane & 31) * DRS + (lane >> 5) * 32;
+
+    typedef __attribute__((address_space(3))) int lds_int;
+    volatile lds_int* sync_cnt = (volatile lds_int*)(smem + (size_t)WK * 2 * 32 * DRS * sizeof(T)) + wk;
+    if (wn == 0 && lane == 0) *sync_cnt = 0;
+    stage_load(0);  // x first: a wave's loads return in order and this one is L2-resident
+#pragma unroll
+    for (int s = 0; s < DRING; ++s) w_load(s, wq[s]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // publishes the zeroed counters; does not wait for the loads above
+    auto group_sync = [&](int target) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add((lds_int*)sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__builtin_amdgcn_readfirstlane(*sync_cnt) < target) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    stage_store(0);
+    group_sync(TN);
+
+    auto chunk_body = [&](const int chunk, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        if (!LAST) stage_load(chunk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const T* xbuf = xs + (chunk & 1) * (32 * DRS) + xoff;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int step = chunk * 4 + s4;
+            const T* xk = xbuf + s4 * 64;
+            V8* cur = wq[s4 & (DRING - 1)];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 V8 av = ld16<V8>(xk + i * 8);
-                acc = mfma32(av, wv[s][i], acc);
+                accs[i & 1] = mfma32(av, cur[i], accs[i & 1]);
+            }
+            // the slot is consumed: refill it in place, DRING steps ahead (the last chunk only refills what it
+            // will still consume itself)
+            if (!LAST || s4 + DRING < 4) {
+                __builtin_amdgcn_sched_barrier(0);
+                w_load(step + DRING, cur);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (LAST) return;
+        stage_store((chunk + 1) & 1);
+        group_sync(TN * (chunk + 2));
+    };
+    for (int chunk = 0; chunk + 1 < nchunks; ++chunk) chunk_body(chunk, std::false_type{});
+    chunk_body(nchunks - 1, std::true_type{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every k-part is done with its x buffers: the reduction below reuses them
 
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-    {
-        float* dst = red + ((wk * WN + wn) << 10);
-        const int col = lane & 31;
+    f32x16 acc = accs[0] + accs[1];
+    if (WK > 1) {
+        float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][64 lanes][16]
+        if (wk > 0) {
+            float* dst = red + (((wk * TN + wn) * 64 + lane) << 4);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            dst[row * 32 + col] = acc[r];
+            for (int r = 0; r < 16; r += 4)
+                *reinterpret_cast<f32x4*>(dst + r) = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wk > 0) return;
+#pragma unroll
+        for (int k2 = 1; k2 < WK; ++k2) {
+            const float* src = red + (((k2 * TN + wn) * 64 + lane) << 4);
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(src + r);
+                acc[r] += t[0];
+                acc[r + 1] += t[1];
+                acc[r + 2] += t[2];
+                acc[r + 3] += t[3];
+            }
         }
     }
-    __syncthreads();
-    auto emit = [&](int m, int n, f32x4 v) {
-        for (int e = 0; e < 4; ++e) {
-            if (n + e < a.N) {
-                float f = v[e];
-                if (a.bias) f += to_f32(reinterpret_cast<const T*>(a.bias)[n + e]);
-                if (a.out_f32)
-                    reinterpret_cast<float*>(a.out)[(int64_t)m * a.ldo + n + e] = f;
-                else
-                    reinterpret_cast<T*>(a.out)[(int64_t)m * a.ldo + n + e] = from_f32<T>(f);
-            }
-        }
-    };
-    for (int o = tid; o < WN * 256; o += DTHREADS) {
-        int wn2 = o >> 8, m = (o >> 3) & 31, c4 = (o & 7) * 4;
-        int nt2 = ntg * WN + wn2;
-        if (nt2 >= a.NT) continue;
-        f32x4 v = {0, 0, 0, 0};
+
+    // ---- epilogue: lane holds out[m = (r&3)+8(r>>2)+4(lane>>5)][n = nt*32 + (lane&31)] ------------
+    if (nt_raw >= a.NT) return;
+    const int n = nt * 32 + (lane & 31);
+    if (a.S == 1 && !a.partial) {
+        if (n >= a.N) return;
+        const float bv = a.bias ? to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
 #pragma unroll
-        for (int k2 = 0; k2 < WK; ++k2)
-            v += *reinterpret_cast<const f32x4*>(red + ((k2 * WN + wn2) << 10) + m * 32 + c4);
-        if (a.S == 1) {
-            if (m < a.M) emit(m, nt2 * 32 + c4, v);
-        } else {
-            *reinterpret_cast<f32x4*>(a.slabs + (((int64_t)split * a.NT + nt2) << 10) + m * 32 + c4) = v;
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= mrows) continue;
+            if (a.out_f32)
+                reinterpret_cast<float*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = acc[r] + bv;
+            else
+                reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = from_f32<T>(acc[r] + bv);
+        }
+    } else {
+        float* sl = a.slabs + ((int64_t)(mslab * a.S + split) * 32) * (a.NT * 32) + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            sl[(int64_t)m * (a.NT * 32)] = acc[r];
         }
     }
 }
 
 // Sum the S split-K slabs in fixed order and emit the output (+bias); thread = (row, 4 columns).
 template <typename T>
-__global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(DenseArgs a) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)a.NT * 256) return;
-    int c4 = (idx & 7) * 4, m = (idx >> 3) & 31;
-    int64_t nt = idx >> 8;
-    if (m >= a.M) return;
+__global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float* __restrict__ slabs,
+                                                                  const T* __restrict__ bias, void* __restrict__ out,
+                                                                  int64_t ldo, int M, int N, int NP, int S, int out_f32) {
+    const int np4 = NP >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int mslab = blockIdx.y;
+    if (idx >= (int64_t)32 * np4) return;
+    const int m = idx / np4, c4 = (idx - (int64_t)m * np4) * 4;
+    if (mslab * 32 + m >= M) return;
     f32x4 v = {0, 0, 0, 0};
-    for (int s2 = 0; s2 < a.S; ++s2)
-        v += *reinterpret_cast<const f32x4*>(a.slabs + (((int64_t)s2 * a.NT + nt) << 10) + m * 32 + c4);
-    int64_t n = nt * 32 + c4;
+    const float* base = slabs + ((int64_t)mslab * S * 32 + m) * NP + c4;
+    for (int s2 = 0; s2 < S; ++s2) v += *reinterpret_cast<const f32x4*>(base + (int64_t)s2 * 32 * NP);
+#pragma unroll
     for (int e = 0; e < 4; ++e) {
-        if (n + e < a.N) {
-            float f = v[e];
-            if (a.bias) f += to_f32(reinterpret_cast<const T*>(a.bias)[n + e]);
-            if (a.out_f32)
-                reinterpret_cast<float*>(a.out)[(int64_t)m * a.ldo + n + e] = f;
-            else
-                reinterpret_cast<T*>(a.out)[(int64_t)m * a.ldo + n + e] = from_f32<T>(f);
-        }
+        if (c4 + e >= N) continue;
+        float f = v[e] + (bias ? to_f32(bias[c4 + e]) : 0.f);
+        const int64_t o = (int64_t)(mslab * 32 + m) * ldo + c4 + e;
+        if (out_f32)
+            reinterpret_cast<float*>(out)[o] = f;
+        else
+            reinterpret_cast<T*>(out)[o] = from_f32<T>(f);
     }
 }
 
 struct DensePlan {
-    int WN, KB, S;
-    size_t lds;
+    int KR, S, WK, TN;
 };
 
+// Same shape rules as plan_gemm (gptq.hip) — the bytes per tile are 4x, the block structure is the same.
 static DensePlan plan_dense(int64_t K, int64_t N) {
-    int64_t NT = cdiv64(N, 32);
-    DensePlan best = {1, 1024, 1, 0};
-    double best_cost = 1e30;
-    const int wns[4] = {1, 2, 4, 8};
-    for (int wi = 0; wi < 4; ++wi) {
-        int WN = wns[wi], WK = 8 / WN;
-        int64_t kbmax = std::min<int64_t>(2048, (int64_t)DMAXSTEPS * 64 * WK);
-        for (int64_t S = 1; S <= 64; ++S) {
-            int64_t KB = cdiv64(cdiv64(K, S), 64) * 64;
-            if (KB > kbmax) continue;
-            if ((S - 1) * KB >= K) continue;
-            int64_t blocks = cdiv64(NT, WN) * S;
-            size_t lds = std::max<size_t>(32 * (KB + 8) * 2, 8 * 4096);
-            int per_cu = std::min<int>(4, (int)(160 * 1024 / (lds + 64)));
-            if (per_cu < 1) continue;
-            double rounds = (double)blocks / (256.0 * per_cu);
-            double fill = rounds < 1.0 ? 1.0 : (std::ceil(rounds) / rounds);
-            double wbytes = (double)K * N * 2;
-            double xbytes = (double)blocks * 32 * KB * 2 * 0.25;
-            double sbytes = S > 1 ? (double)S * 32 * N * 4 * 2.0 : 0.0;
-            double under = blocks < 256 ? 256.0 / blocks : 1.0;
-            double cost = (wbytes + xbytes + sbytes) * fill * under;
-            if (cost < best_cost) {
-                best_cost = cost;
-                best = {WN, (int)KB, (int)S, lds};
-            }
-        }
+    const int64_t tiles = cdiv64(N, 32);
+    const int64_t kchunks = cdiv64(K, DKC);
+    int TN, WK;
+    int64_t S = 1;
+    if (tiles >= 512) {
+        TN = cdiv64(tiles, 3) <= 256 ? 3 : 4;
+        WK = 4;
+    } else {
+        TN = tiles >= 256 ? 4 : 2;
+        const int64_t colblocks = cdiv64(tiles, TN);
+        const int64_t want = TN == 4 ? 224 : 256;
+        S = std::max<int64_t>(1, std::min<int64_t>(kchunks, (want + colblocks / 2) / colblocks));
+        while (S > 1 && (S - 1) * cdiv64(kchunks, S) >= kchunks) --S;
+        WK = TN == 4 ? 2 : (cdiv64(kchunks, S) >= 4 ? 4 : 2);
     }
-    return best;
+    int64_t KRc = cdiv64(kchunks, S);
+    if (KRc < WK) WK = 2;
+    KRc = cdiv64(KRc, WK) * WK;
+    while (S > 1 && (S - 1) * KRc >= kchunks) --S;
+    return {(int)(KRc * DKC), (int)S, WK, TN};
 }
 
-template <typename T, int WN, int ACT>
-static int launch_dense(const DenseArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+static int64_t dense_slab_bytes(int64_t M, int64_t N, int S) { return cdiv64(M, 32) * S * 32 * cdiv64(N, 32) * 32 * 4; }
+
+template <typename T, int TN, int WK, int ACT>
+static int launch_dense_variant(dim3 grid, size_t lds, hipStream_t st, const DenseArgs& a) {
     static bool attr = false;
     if (!attr) {
-        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)dense_gemm_kernel<T, WN, ACT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)dense_gemm_kernel<T, TN, WK, ACT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * DRS * 2 + 64));
         attr = true;
     }
-    hipLaunchKernelGGL((dense_gemm_kernel<T, WN, ACT>), grid, dim3(DTHREADS), lds, st, a);
-    TGIS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((dense_gemm_kernel<T, TN, WK, ACT>), grid, dim3(64 * TN * WK), lds, st, a);
     return TGIS_OK;
 }
 
 template <typename T>
-static int dispatch_dense(const DenseArgs& a, int WN, int act, dim3 grid, size_t lds, hipStream_t st) {
-    switch (WN * 2 + act) {
-        case 2: return launch_dense<T, 1, 0>(a, grid, lds, st);
-        case 3: return launch_dense<T, 1, 1>(a, grid, lds, st);
-        case 4: return launch_dense<T, 2, 0>(a, grid, lds, st);
-        case 5: return launch_dense<T, 2, 1>(a, grid, lds, st);
-        case 8: return launch_dense<T, 4, 0>(a, grid, lds, st);
-        case 9: return launch_dense<T, 4, 1>(a, grid, lds, st);
-        case 16: return launch_dense<T, 8, 0>(a, grid, lds, st);
-        case 17: return launch_dense<T, 8, 1>(a, grid, lds, st);
+static int launch_dense(const DenseArgs& a, const DensePlan& pl, int act, int64_t mslabs, hipStream_t st) {
+    dim3 grid((unsigned)cdiv64(a.NT, pl.TN), (unsigned)pl.S, (unsigned)mslabs);
+    const size_t lds = (size_t)pl.WK * 2 * 32 * DRS * sizeof(T) + 64;
+    int rc = TGIS_EINVAL;
+#define TGIS_DENSE_CASE(T_, W_)                                                        \
+    if (pl.TN == T_ && pl.WK == W_)                                                    \
+        rc = act ? launch_dense_variant<T, T_, W_, 1>(grid, lds, st, a) : launch_dense_variant<T, T_, W_, 0>(grid, lds, st, a)
+    TGIS_DENSE_CASE(2, 2);
+    TGIS_DENSE_CASE(2, 4);
+    TGIS_DENSE_CASE(3, 4);
+    TGIS_DENSE_CASE(4, 2);
+    TGIS_DENSE_CASE(4, 4);
+#undef TGIS_DENSE_CASE
+    if (rc != TGIS_OK) {
+        tgis_set_error("tgis_dense_gemm: no kernel for plan TN=%d WK=%d", pl.TN, pl.WK);
+        return rc;
     }
-    tgis_set_error("dispatch_dense: bad WN/act");
-    return TGIS_EINVAL;
+    TGIS_CHECK_LAUNCH();
+    if (!a.partial && pl.S > 1) {
+        const int NP = a.NT * 32;
+        dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 4), 256), (unsigned)mslabs);
+        hipLaunchKernelGGL(dense_splitk_reduce_kernel<T>, rgrid, dim3(256), 0, st, a.slabs, (const T*)a.bias, a.out, a.ldo,
+                           a.M, a.N, NP, a.S, a.out_f32);
+        TGIS_CHECK_LAUNCH();
+    }
+    return TGIS_OK;
 }
 
 }  // namespace
@@ -285,56 +368,80 @@ extern "C" int tgis_dense_prepare(const void* w, int64_t N, int64_t K, int dtype
 }
 
 extern "C" int64_t tgis_dense_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N) {
-    (void)M;
     DensePlan pl = plan_dense(K, N);
-    return 4096 + (pl.S > 1 ? (int64_t)pl.S * cdiv64(N, 32) * 4096 : 0);
+    return 4096 + (pl.S > 1 ? dense_slab_bytes(M, N, pl.S) : 0);
+}
+
+static int dense_check(const void* x, int64_t ldx, const void* prepared, int64_t M, int64_t K, int64_t N, int dtype,
+                       int act) {
+    TGIS_CHECK_ARG(x && prepared, "tgis_dense_gemm: null tensor");
+    TGIS_CHECK_ARG(M >= 0 && K > 0 && N > 0, "tgis_dense_gemm: bad shape");
+    TGIS_CHECK_ARG(K % 8 == 0, "tgis_dense_gemm: K (%ld) must be a multiple of 8", (long)K);
+    TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "tgis_dense_gemm: bad dtype");
+    TGIS_CHECK_ARG(act == 0 || act == 1, "tgis_dense_gemm: act must be 0 or 1");
+    TGIS_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, "tgis_dense_gemm: x rows must be 16-byte aligned");
+    return TGIS_OK;
+}
+
+static void dense_fill(DenseArgs& a, const void* x, int64_t ldx, const void* prepared, const void* bias, void* out,
+                       int64_t ldo, int64_t M, int64_t K, int64_t N, int out_f32, float* slabs, int partial,
+                       const DensePlan& pl) {
+    a.x = x;
+    a.ldx = ldx;
+    a.prep = (const uint8_t*)prepared;
+    a.bias = bias;
+    a.out = out;
+    a.ldo = ldo;
+    a.M = (int)M;
+    a.K = (int)K;
+    a.N = (int)N;
+    a.KR = pl.KR;
+    a.S = pl.S;
+    a.NT = (int)cdiv64(N, 32);
+    a.KS = (int)cdiv64(K, 64);
+    a.out_f32 = out_f32;
+    a.slabs = slabs;
+    a.partial = partial;
 }
 
 extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared, const void* bias, void* out,
                                int64_t ldo, int64_t M, int64_t K, int64_t N, int dtype, int out_f32, int act,
                                void* workspace, int64_t workspace_bytes, void* stream) {
-    TGIS_CHECK_ARG(x && prepared && out, "tgis_dense_gemm: null tensor");
-    TGIS_CHECK_ARG(M >= 0 && K > 0 && N > 0, "tgis_dense_gemm: bad shape");
-    TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "tgis_dense_gemm: bad dtype");
-    TGIS_CHECK_ARG(act == 0 || act == 1, "tgis_dense_gemm: act must be 0 or 1");
-    TGIS_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, "tgis_dense_gemm: x rows must be 16-byte aligned");
+    int rc = dense_check(x, ldx, prepared, M, K, N, dtype, act);
+    if (rc != TGIS_OK) return rc;
+    TGIS_CHECK_ARG(out, "tgis_dense_gemm: null out");
     if (M == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
     DensePlan pl = plan_dense(K, N);
-    int64_t NT = cdiv64(N, 32), KS = cdiv64(K, 64);
-    int64_t need = 4096 + (pl.S > 1 ? (int64_t)pl.S * NT * 4096 : 0);
+    const int64_t need = tgis_dense_gemm_workspace_bytes(M, K, N);
     TGIS_CHECK_ARG(workspace && workspace_bytes >= need, "tgis_dense_gemm: workspace too small (%ld < %ld)",
                    (long)workspace_bytes, (long)need);
     TgisTimedScope timed(TGIS_OP_DENSE_GEMM, st);
     DenseArgs a;
-    a.prep = prepared;
-    a.bias = bias;
-    a.ldx = ldx;
-    a.ldo = ldo;
-    a.K = (int)K;
-    a.N = (int)N;
-    a.KB = pl.KB;
-    a.S = pl.S;
-    a.NT = (int)NT;
-    a.KS = (int)KS;
-    a.out_f32 = out_f32;
-    a.slabs = (float*)((uint8_t*)workspace + 4096);
-    dim3 grid((unsigned)cdiv64(NT, pl.WN), (unsigned)pl.S);
-    const int64_t esz_out = out_f32 ? 4 : 2;
-    for (int64_t m0 = 0; m0 < M; m0 += 32) {
-        a.x = (const uint8_t*)x + m0 * ldx * 2;
-        a.out = (uint8_t*)out + m0 * ldo * esz_out;
-        a.M = (int)std::min<int64_t>(32, M - m0);
-        int rc = dtype == TGIS_F16 ? dispatch_dense<f16>(a, pl.WN, act, grid, pl.lds, st)
-                                   : dispatch_dense<bf16>(a, pl.WN, act, grid, pl.lds, st);
-        if (rc != TGIS_OK) return rc;
-        if (pl.S > 1) {
-            if (dtype == TGIS_F16)
-                hipLaunchKernelGGL(dense_splitk_reduce_kernel<f16>, dim3((unsigned)NT), dim3(256), 0, st, a);
-            else
-                hipLaunchKernelGGL(dense_splitk_reduce_kernel<bf16>, dim3((unsigned)NT), dim3(256), 0, st, a);
-            TGIS_CHECK_LAUNCH();
-        }
-    }
-    return TGIS_OK;
+    dense_fill(a, x, ldx, prepared, bias, out, ldo, M, K, N, out_f32, (float*)((uint8_t*)workspace + 4096), 0, pl);
+    return dtype == TGIS_F16 ? launch_dense<f16>(a, pl, act, cdiv64(M, 32), st)
+                             : launch_dense<bf16>(a, pl, act, cdiv64(M, 32), st);
+}
+
+extern "C" int64_t tgis_dense_gemm_partial_bytes(int64_t K, int64_t N) {
+    DensePlan pl = plan_dense(K, N);
+    return dense_slab_bytes(32, N, pl.S);
+}
+
+extern "C" int tgis_dense_gemm_partial(const void* x, int64_t ldx, const void* prepared, int64_t M, int64_t K,
+                                       int64_t N, int dtype, int act, float* slabs, int64_t slabs_bytes,
+                                       int* num_slabs, int64_t* slab_ld, void* stream) {
+    int rc = dense_check(x, ldx, prepared, M, K, N, dtype, act);
+    if (rc != TGIS_OK) return rc;
+    TGIS_CHECK_ARG(M >= 1 && M <= 32, "tgis_dense_gemm_partial: M must be in 1..32");
+    TGIS_CHECK_ARG(slabs && slabs_bytes >= tgis_dense_gemm_partial_bytes(K, N),
+                   "tgis_dense_gemm_partial: slab buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    DensePlan pl = plan_dense(K, N);
+    if (num_slabs) *num_slabs = pl.S;
+    if (slab_ld) *slab_ld = cdiv64(N, 32) * 32;
+    TgisTimedScope timed(TGIS_OP_DENSE_GEMM, st);
+    DenseArgs a;
+    dense_fill(a, x, ldx, prepared, nullptr, nullptr, 0, M, K, N, 0, slabs, 1, pl);
+    return dtype == TGIS_F16 ? launch_dense<f16>(a, pl, act, 1, st) : launch_dense<bf16>(a, pl, act, 1, st);
 }

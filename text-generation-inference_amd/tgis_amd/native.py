@@ -48,6 +48,9 @@ SIGNATURES = {
     "tgis_dense_gemm_workspace_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
     "tgis_dense_gemm": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int,
                                  _c_int, _vp, _c_i64, _vp]),
+    "tgis_dense_gemm_partial_bytes": (_c_i64, [_c_i64, _c_i64]),
+    "tgis_dense_gemm_partial": (_c_int, [_vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _vp, _c_i64,
+                                         ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64), _vp]),
     "tgis_rmsnorm_residual": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f, _c_int, _vp]),
     "tgis_rmsnorm_residual_partial": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f,
                                                _c_int, _vp]),
@@ -292,6 +295,23 @@ def dense_gemm(x: torch.Tensor, w: DenseWeight, ws: Workspace, bias=None, out_f3
                                        w.K, w.N, dtype_code(w.dtype), int(out_f32), act, ws.ptr, ws.nbytes,
                                        _stream()), "tgis_dense_gemm")
     return out
+
+
+def dense_gemm_partial(x: torch.Tensor, w: DenseWeight, bias=None, act: int = 0) -> Partial:
+    """Launch the dense GEMM but leave the split-K reduce (and bias) to the consumer kernel.  M <= 32."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == w.dtype and x.shape[0] <= 32
+    lib = load_library()
+    nbytes = lib.tgis_dense_gemm_partial_bytes(w.K, w.N)
+    slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    S = _c_int()
+    ld = _c_i64()
+    _check(
+        lib.tgis_dense_gemm_partial(_ptr(x), x.stride(0), _ptr(w.image), x.shape[0], w.K, w.N, dtype_code(w.dtype), act,
+                                    _ptr(slabs), nbytes, ctypes.byref(S), ctypes.byref(ld), _stream()),
+        "tgis_dense_gemm_partial")
+    p = Partial(slabs, S.value, ld.value, x.shape[0], w.N, bias)
+    p.dtype = w.dtype
+    return p
 
 
 # ---- norms --------------------------------------------------------------------------------------------

@@ -41,6 +41,9 @@ class FastLinear:
         self.out_features, self.in_features = weight.shape
 
     def forward(self, x: torch.Tensor, act: int = 0, out_f32: bool = False, partial: bool = False) -> torch.Tensor:
+        if partial and x.shape[0] <= 32 and DEFER_REDUCE and not out_f32:
+            # the split-K sum (and the bias) is finished by the consumer kernel (add+norm / rope): no reduce launch
+            return native.dense_gemm_partial(x, self.prepared, bias=self.bias, act=act)
         if x.shape[0] <= SKINNY_MAX_M:
             return native.dense_gemm(x, self.prepared, workspace(x.device), bias=self.bias, out_f32=out_f32, act=act)
         if act:
