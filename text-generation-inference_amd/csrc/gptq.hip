@@ -148,8 +148,15 @@ __device__ long long* g_trace = nullptr;  // [blocks][16 waves][32 stamps] of s_
             g_trace[((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 +       \
                      __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+#define TRACE_RT(i)                                                                                         \
+    do {                                                                                                    \
+        if (g_trace)                                                                                        \
+            g_trace[((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 +       \
+                     __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
 #define TRACE(i)
+#define TRACE_RT(i)
 #endif
 
 #define GLOBAL_AS __attribute__((address_space(1)))  // asm-pinned pointers lose their address space: restate it
@@ -180,6 +187,7 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
     // SGPRs so that the address/clamp arithmetic of the loop runs on the scalar unit, not on the VALU that the
     // dequantisation saturates
     TRACE(0);
+    TRACE_RT(14);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = w % TN, wk = w / TN, ltid = wn * 64 + lane;
     f16* xs = reinterpret_cast<f16*>(smem) + wk * (2 * 32 * RS);  // this k-part's [2][32][RS]
@@ -420,6 +428,7 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
 
     // ---- epilogue: lane holds out[m = (r&3)+8(r>>2)+4(lane>>5)][n = nt*32 + (lane&31)] ------------
     TRACE(12);
+    TRACE_RT(15);
     if (nt_raw >= a.NT) return;
     const int n = nt * 32 + (lane & 31);
     if (ACT == 2) {

@@ -83,3 +83,13 @@ for a_, b_ in pairs:
     if m.any():
         d = (vb[m] - va[m]).float()
         print(f"  dt {names[a_]:>24s} -> {names[b_]:24s} p50={d.median():8.0f} p90={torch.quantile(d, 0.9):8.0f} max={d.max():8.0f}")
+
+# chip-wide picture from s_memrealtime (100 MHz): when do waves enter, when do reducer waves reach the epilogue
+rt0, rt1 = t[:, :, 14], t[:, :, 15]
+m0, m1 = rt0 != 0, rt1 != 0
+base = rt0[m0].min().item()
+e = (rt0[m0] - base).float() * 10.0
+x = (rt1[m1] - base).float() * 10.0
+qs = torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0])
+print("  realtime ns since first wave entry:  entry  ", [int(v) for v in torch.quantile(e, qs)])
+print("                                       epilogue", [int(v) for v in torch.quantile(x, qs)])
