@@ -165,14 +165,16 @@ __device__ long long* g_trace = nullptr;  // [blocks][16 waves][32 stamps] of s_
 constexpr int KC = 256;     // k per LDS chunk (4 k64-steps)
 constexpr int RS = KC + 8;  // LDS row stride in halves (+16 B -> conflict-free ds_read_b128)
 
-// Streaming kernel: a block of 4*WK waves owns 128 columns x [k0,k1) of W.  Wave w works on column tile
-// (w & 3) and k-part (w >> 2): it streams its own 32-column tile over its own contiguous KR/WK rows (1 KiB per
-// load, one chunk = 4 loads ahead) while each k-part group of 4 waves double-buffers its 32 x 256 chunks of x
-// through its own LDS region.  The WK partial accumulators are summed through LDS at the end (fixed order), so
-// in-block k-parts add waves per SIMD without slab traffic.  The main loop is branch-free (clamped addresses +
-// selects) so that hipcc keeps counted vmcnt waits and the prefetched loads stay in flight across the barriers.
-// GROUP64: group size is a multiple of 64 (one scale/zero per lane per step, prefetched with the weights).
-// TN = column tiles (waves) per k-part: 4 (128 columns per block) or 2 (64 columns; more blocks for narrow N).
+// Streaming kernel: a block of TN*WK waves owns 32*TN columns x [k0,k1) of W.  Wave w works on column tile w % TN and
+// k-part w / TN: it streams its own 32-column tile over its own contiguous KR/WK rows (1 KiB per load, one chunk = 4
+// loads in flight, each slot refilled in place right after it is consumed) while every k-part group of TN waves
+// double-buffers its 32 x 256 chunks of x through its own LDS region and paces itself with an LDS arrival counter (the
+// block-wide barrier is only used to publish the zeroed counters and before the final reduction).  The WK partial
+// accumulators are summed through LDS at the end (fixed order), so in-block k-parts add waves per SIMD without slab
+// traffic.  The main loop is branch-free (clamped addresses, zero scales past the wave's rows) so that hipcc keeps
+// counted vmcnt waits; everything wave-uniform lives in SGPRs.
+// GROUP64: group size is 64 * 2^n (one scale/zero per lane per step, prefetched with the weights).
+// TN = column tiles (waves) per k-part: 2, 3 or 4; WK = k-parts per block: 2 or 4 (plan_gemm).
 template <int TN, int WK, int ACT, bool GROUP64, bool PERM>
 __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
     // one chunk (4 one-KiB loads) of weights in flight per wave.  Measured: a two-chunk ring is ~1 us SLOWER on every
