@@ -323,3 +323,42 @@ def test_prompt_prefix_equals_the_same_tokens_in_the_prompt(gpu_device, tmp_path
     for a, b in zip(logits_t, logits_p):
         np.testing.assert_allclose(a, b, atol=1e-3)
     assert lm.kv_cache.free_pages == lm.kv_cache.num_pages
+
+
+@pytest.mark.parametrize("variant", [None, "gptq"])
+def test_batch_larger_than_one_row_slab_matches_oracle(gpu_device, variant):
+    """B = 40 decode rows: two 32-row slabs in every skinny GEMM, no deferred split-K (Partial is for M <= 32), more
+    (sequence, kv head) blocks in attention; then a prune down to 33 and to 5 rows changes the captured graph shape."""
+    cfg = TinyLlamaConfig()
+    tensors = tiny_llama_tensors(cfg, seed=13, quantize=variant, groupsize=64)
+    lm, tok = _build(cfg, tensors, variant, 64, torch.float16)
+    tap = _LogitTap(lm)
+    rng = np.random.default_rng(17)
+    B = 40
+    prompts = [rng.integers(3, cfg.vocab_size, size=int(n)).tolist() for n in rng.integers(1, 50, size=B)]
+    batch = _from_pb(lm, tok, _pb(prompts, 8))
+    ref = LlamaRef(cfg, tensors, quantize=variant, groupsize=64)
+    got = [_step(lm, batch, tap, first=True)] + [_step(lm, batch, tap) for _ in range(2)]
+    want = ref.generate_greedy(prompts, 3, forced=[[t.token_id for t in toks] for toks, _ in got])
+    for i, ((toks, logits), w) in enumerate(zip(got, want)):
+        step = {"ids": w["token_ids"].numpy(), "logits": w["logits"].numpy(), "logprobs": w["logprobs"].numpy(),
+                "request_ids": np.arange(B)}
+        _check_step(toks, logits, step, torch.float16, f"B=40 step {i}")
+    # prune to 33 rows (still two slabs), then to 5: the survivors continue exactly as the oracle's same sequences
+    history = [[t.token_id for t in toks] for toks, _ in got]
+    for keep in (list(range(0, 40))[:33], [1, 4, 9, 20, 32]):
+        keep_ids = [batch.requests[i].id for i in range(len(batch.requests)) if batch.requests[i].id in set(keep)]
+        batch = lm.batch_type.prune(batch, [r.id for r in batch.requests if r.id not in set(keep_ids)])
+        toks, logits = _step(lm, batch, tap)
+        assert [t.request_id for t in toks] == keep_ids
+        sub_prompts = [prompts[i] for i in keep_ids]
+        sub_hist = [[h[i] for i in keep_ids] for h in history]
+        w = ref.generate_greedy(sub_prompts, len(history) + 1, forced=sub_hist + [[t.token_id for t in toks]])[-1]
+        step = {"ids": w["token_ids"].numpy(), "logits": w["logits"].numpy(), "logprobs": w["logprobs"].numpy(),
+                "request_ids": np.array(keep_ids)}
+        _check_step(toks, logits, step, torch.float16, f"after prune to {len(keep_ids)}")
+        history.append([0] * B)
+        for t in toks:
+            history[-1][t.request_id] = t.token_id
+    batch.release()
+    assert lm.kv_cache.free_pages == lm.kv_cache.num_pages, "pages leaked"
