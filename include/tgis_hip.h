@@ -160,6 +160,15 @@ int tgis_rope_kv_write_partial(const float* slabs, int num_slabs, int64_t slab_l
                                const int32_t* slots, void* k_pool, void* v_pool, int64_t T, int H, int Hkv, int D,
                                int rot_dim, int dtype, void* stream);
 
+/* Prefill form of tgis_rope_kv_write for fresh sequences (token i of sequence b is cache position i): q is rotated in
+ * place; k (rotated) and v go to the cache page by page — full 16-byte runs of the page layouts instead of the
+ * per-token scatter — with the slots of a last partial page zeroed.  k/v inside `qkv` are left as they came.
+ *   cu_seqlens [B+1]: token offsets; block_tables [B, max_pages]; T = total tokens; max_len = longest sequence. */
+int tgis_rope_kv_write_prefill(void* qkv, int64_t ld_qkv, const void* cos, const void* sin, const int32_t* positions,
+                               const int32_t* cu_seqlens, const int32_t* block_tables, int64_t max_pages, void* k_pool,
+                               void* v_pool, int64_t B, int64_t T, int64_t max_len, int H, int Hkv, int D, int rot_dim,
+                               int dtype, void* stream);
+
 /* ---- paged attention, prefill and decode (replaces flash_attn_2_cuda.varlen_fwd,
  *      utils/flash_attn.py:43-78) ---------------------------------------------------------------- */
 /* Number of key-range splits the launcher will use for this shape (so callers can size workspace). */

@@ -92,6 +92,14 @@ def _rope_kv_write(qkv, cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, r
     return qkv
 
 
+def _rope_kv_write_prefill(qkv, cos, sin, positions, cu_seqlens, block_tables, k_pool, v_pool, max_len, H, Hkv, D, rot_dim):
+    # by contract the per-token kernel with slot(b, i) = block_tables[b][i // 32] * 32 + i % 32
+    cu = [int(v) for v in cu_seqlens]
+    slots = torch.tensor([int(block_tables[b, i // 32]) * 32 + i % 32
+                          for b in range(len(cu) - 1) for i in range(cu[b + 1] - cu[b])], dtype=torch.int32)
+    return _rope_kv_write(qkv, cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, rot_dim)
+
+
 def _attn_paged(q, ld_q, k_pool, v_pool, block_tables, ctx_lens, cu_q, out, B, H, Hkv, D, max_q_len, max_ctx, scale,
                 num_splits, ws):
     store = _POOLS[k_pool.data_ptr()]
@@ -138,7 +146,7 @@ def install(monkeypatch):
     for name, fn in dict(
         Workspace=_Workspace, GptqWeight=_GptqWeight, DenseWeight=_DenseWeight, gptq_gemm=_gptq_gemm,
         dense_gemm=_dense_gemm, rmsnorm_residual=_rmsnorm, layernorm_residual=_layernorm,
-        rope_kv_write=_rope_kv_write, attn_paged=_attn_paged, embedding=_embedding, decode_slots=_decode_slots,
+        rope_kv_write=_rope_kv_write, rope_kv_write_prefill=_rope_kv_write_prefill, attn_paged=_attn_paged, embedding=_embedding, decode_slots=_decode_slots,
         argmax_logprob=_argmax_logprob, attn_num_splits=lambda *a: 1, attn_workspace_bytes=lambda *a: 0,
         act_mul=lambda gu, I, out=None: ops_ref.silu_mul(gu, I).to(gu.dtype),
         gptq_gemm_partial=lambda x, w, bias=None, act=0: _gptq_gemm(x, w, None, bias=bias, act=act),

@@ -378,3 +378,41 @@ def test_dense_partial_then_rmsnorm_is_bit_identical_to_unfused(nat, gpu_device,
         assert part.S > 1, "this shape is meant to exercise a real split"
     y1, r1 = nat.rmsnorm_residual(part, res, wn, 1e-5)
     assert torch.equal(y0, y1) and torch.equal(r0, r1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("H,Hkv,D,rope", [(8, 8, 128, True), (8, 2, 64, True), (12, 1, 128, False)])
+def test_rope_kv_write_prefill_is_bit_identical_to_per_token_kernel(nat, gpu_device, dtype, H, Hkv, D, rope):
+    """Page-wise prefill cache write == per-token kernel: rotated q rows, every valid cache slot, zeros in the tail of a
+    last partial page (the per-token kernel leaves those untouched: compared against a zeroed pool)."""
+    lens = [1, 31, 32, 33, 64, 100, 7]
+    B, T = len(lens), sum(lens)
+    g = torch.Generator().manual_seed(H * 7 + D)
+    pages_per = (max(lens) + 31) // 32
+    total = B * pages_per + 1
+    bt = torch.randperm(total, generator=g)[: B * pages_per].int().view(B, pages_per).contiguous().to(gpu_device)
+    qkv = torch.randn(T, (H + 2 * Hkv) * D, generator=g).to(dtype).to(gpu_device)
+    cos = sin = None
+    if rope:
+        cos, sin = ops_ref.rope_tables(D, 10000.0, 128, dtype)
+        cos, sin = cos.to(gpu_device), sin.to(gpu_device)
+    pos = torch.cat([torch.arange(l) for l in lens]).int().to(gpu_device)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=gpu_device)
+    slots = torch.cat([bt[b, torch.arange(l, device=gpu_device) // 32].long() * 32 + torch.arange(l, device=gpu_device) % 32
+                       for b, l in enumerate(lens)]).int()
+    pools = [(torch.zeros(total, Hkv, 32 * D, dtype=dtype, device=gpu_device),
+              torch.zeros(total, Hkv, 32 * D, dtype=dtype, device=gpu_device)),
+             (torch.full((total, Hkv, 32 * D), 7.0, dtype=dtype, device=gpu_device),   # stale data the page-wise kernel
+              torch.full((total, Hkv, 32 * D), 7.0, dtype=dtype, device=gpu_device))]  # must overwrite in used pages
+    q0 = qkv.clone()
+    nat.rope_kv_write(q0, cos, sin, pos, slots, pools[0][0], pools[0][1], H, Hkv, D, D)
+    q1 = qkv.clone()
+    nat.rope_kv_write_prefill(q1, cos, sin, pos, cu, bt, pools[1][0], pools[1][1], max(lens), H, Hkv, D, D)
+    torch.cuda.synchronize()
+    assert torch.equal(q0[:, :H * D], q1[:, :H * D]), "rotated q"
+    assert torch.equal(q1[:, H * D:], qkv[:, H * D:]), "k/v columns of qkv are left as they came"
+    used = torch.cat([bt[b, :(l + 31) // 32] for b, l in enumerate(lens)]).long()
+    assert torch.equal(pools[0][0][used], pools[1][0][used]), "K pages"
+    assert torch.equal(pools[0][1][used], pools[1][1][used]), "V pages"
+    unused = torch.tensor(sorted(set(range(total)) - set(used.tolist())), device=gpu_device)
+    assert (pools[1][0][unused] == 7.0).all() and (pools[1][1][unused] == 7.0).all(), "pages of other sequences untouched"

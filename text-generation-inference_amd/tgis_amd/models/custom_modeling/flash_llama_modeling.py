@@ -70,6 +70,7 @@ class KVArgs:
     max_q_len: int                     # longest q run in this forward (1 for decode)
     max_ctx: int                       # upper bound of ctx_lens (launch shaping only)
     num_splits: int = 1                # attention key splits (decode)
+    fresh_prefill: bool = False        # every sequence starts at cache position 0: page-wise cache writes
 
 
 class LlamaRMSNorm:
@@ -117,7 +118,11 @@ class FlashLlamaAttention:
         qkv = self.query_key_value(hidden_states, partial=True)
         k_pool, v_pool = kv.cache.k_pool(layer_id), kv.cache.v_pool(layer_id)
         # rotate q,k in place and scatter k,v to their page slots (reference :252-268,282)
-        qkv = native.rope_kv_write(qkv, cos, sin, position_ids, kv.slots, k_pool, v_pool, H, Hkv, D, D)
+        if kv.fresh_prefill and not isinstance(qkv, native.Partial):
+            qkv = native.rope_kv_write_prefill(qkv, cos, sin, position_ids, cu_seqlens_q, kv.block_tables, k_pool, v_pool,
+                                               kv.max_q_len, H, Hkv, D, D)
+        else:
+            qkv = native.rope_kv_write(qkv, cos, sin, position_ids, kv.slots, k_pool, v_pool, H, Hkv, D, D)
         T = qkv.shape[0]
         attn_output = torch.empty((T, H * D), dtype=qkv.dtype, device=qkv.device)
         B = kv.block_tables.shape[0]

@@ -122,7 +122,11 @@ class FlashMQAttention:
         H, D = self.num_heads, self.head_size
         qkv = self.c_attn(hidden_states)  # [T, (H + 2) D]: H query heads, then the single k and v heads
         k_pool, v_pool = kv.cache.k_pool(layer_id), kv.cache.v_pool(layer_id)
-        qkv = native.rope_kv_write(qkv, None, None, None, kv.slots, k_pool, v_pool, H, 1, D, D)  # no rotary
+        if kv.fresh_prefill and not isinstance(qkv, native.Partial):
+            qkv = native.rope_kv_write_prefill(qkv, None, None, None, cu_seqlens_q, kv.block_tables, k_pool, v_pool,
+                                               kv.max_q_len, H, 1, D, D)  # no rotary: page-wise cache write only
+        else:
+            qkv = native.rope_kv_write(qkv, None, None, None, kv.slots, k_pool, v_pool, H, 1, D, D)  # no rotary
         T = qkv.shape[0]
         attn_output = torch.empty((T, H * D), dtype=qkv.dtype, device=qkv.device)
         ws = None

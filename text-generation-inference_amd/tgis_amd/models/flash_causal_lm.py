@@ -267,6 +267,10 @@ class FlashCausalLMBatch(Batch):
         return batch
 
 
+# page-wise cache writes in prefill (tgis_rope_kv_write_prefill); "false" keeps the per-token kernel for A/B checks
+FRESH_PREFILL_KV = os.getenv("TGIS_PREFILL_KV", "true").lower() not in ("0", "false")
+
+
 class _DecodeGraph:
     """Static buffers + captured HIP graph of one decode step for a (batch size, table width) pair."""
 
@@ -409,7 +413,7 @@ class FlashCausalLM(Model):
         kv = KVArgs(cache=self.kv_cache, block_tables=batch.block_tables,
                     ctx_lens=torch.tensor(lens, dtype=torch.int32, device=dev),
                     slots=torch.from_numpy(slots).to(dev, non_blocking=True),
-                    max_q_len=max(lens), max_ctx=max(lens), num_splits=1)
+                    max_q_len=max(lens), max_ctx=max(lens), num_splits=1, fresh_prefill=FRESH_PREFILL_KV)
         self._need_all_logits = any(r.details.input_toks for r in batch.requests)
         lm_head_indices = None if self._need_all_logits else (batch.cu_seqlens[1:] - 1).long()
         return self.model.forward(batch.input_ids, batch.position_ids.to(torch.int32), batch.cu_seqlens,

@@ -59,6 +59,8 @@ SIGNATURES = {
                                     _c_int, _c_int, _vp]),
     "tgis_rope_kv_write_partial": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64,
                                             _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "tgis_rope_kv_write_prefill": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_i64,
+                                            _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "tgis_attn_num_splits": (_c_int, [_c_i64, _c_int, _c_int, _c_i64, _c_i64]),
     "tgis_attn_workspace_bytes": (_c_i64, [_c_i64, _c_int, _c_int, _c_int]),
     "tgis_attn_paged": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_int, _c_int,
@@ -377,6 +379,20 @@ def rope_kv_write(qkv, cos, sin, positions, slots, k_pool, v_pool, H: int, Hkv: 
         load_library().tgis_rope_kv_write(_ptr(qkv), qkv.stride(0), _ptr(cos), _ptr(sin), _ptr(positions),
                                           _ptr(slots), _ptr(k_pool), _ptr(v_pool), T, H, Hkv, D, rot_dim,
                                           dtype_code(qkv.dtype), _stream()), "tgis_rope_kv_write")
+    return qkv
+
+
+def rope_kv_write_prefill(qkv, cos, sin, positions, cu_seqlens, block_tables, k_pool, v_pool, max_len: int, H: int,
+                          Hkv: int, D: int, rot_dim: int):
+    """rope_kv_write for a fresh prefill (token i of a sequence = cache position i): page-wise cache writes."""
+    assert qkv.dim() == 2 and qkv.stride(1) == 1 and block_tables.is_contiguous()
+    B = block_tables.shape[0]
+    _check(
+        load_library().tgis_rope_kv_write_prefill(_ptr(qkv), qkv.stride(0), _ptr(cos), _ptr(sin), _ptr(positions),
+                                                  _ptr(cu_seqlens), _ptr(block_tables), block_tables.shape[1],
+                                                  _ptr(k_pool), _ptr(v_pool), B, qkv.shape[0], max_len, H, Hkv, D,
+                                                  rot_dim, dtype_code(qkv.dtype), _stream()),
+        "tgis_rope_kv_write_prefill")
     return qkv
 
 
