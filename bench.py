@@ -215,7 +215,7 @@ def main():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
         ctx_timed_mean = L_in + 1 + W + (K - 1) / 2.0  # keys attended per step, averaged over the timed steps
-        graphs_kept = bool(lm.use_graphs)  # false if a capture with collectives fell back to eager launches
+        graphs_kept = bool(lm.use_graphs)
 
         roofline = None
         if not args.no_roofline:  # every rank runs it (the forward contains collectives when tp > 1)

@@ -41,6 +41,10 @@ extern "C" {
 const char* tgis_version(void);          /* "tgis_hip x.y (gfx950)" */
 const char* tgis_arch(void);             /* offload arch the kernels were compiled for */
 const char* tgis_last_error(void);       /* thread-local, never NULL */
+/* Forget the last failure, including the HIP runtime's sticky per-thread error: every launch in this library ends with
+ * hipGetLastError(), so an error left behind by someone else's aborted stream capture would otherwise be reported by
+ * the next, unrelated call. */
+void tgis_clear_error(void);
 int tgis_device_info(int device, int* num_cus, int64_t* hbm_bytes, char* name, int name_len);
 
 /* Optional per-op device timing with HIP events recorded on the op's own stream.

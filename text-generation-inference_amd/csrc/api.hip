@@ -17,6 +17,10 @@ void tgis_set_error(const char* fmt, ...) {
 extern "C" const char* tgis_version(void) { return "tgis_hip 0.1 (gfx950)"; }
 extern "C" const char* tgis_arch(void) { return "gfx950"; }
 extern "C" const char* tgis_last_error(void) { return g_err; }
+extern "C" void tgis_clear_error(void) {
+    (void)hipGetLastError();  // the runtime's sticky per-thread error (e.g. left behind by an aborted graph capture)
+    g_err[0] = 0;
+}
 
 extern "C" int tgis_device_info(int device, int* num_cus, int64_t* hbm_bytes, char* name, int name_len) {
     hipDeviceProp_t p;

@@ -29,6 +29,7 @@ _vp = ctypes.c_void_p
 SIGNATURES = {
     "tgis_version": (ctypes.c_char_p, []),
     "tgis_arch": (ctypes.c_char_p, []),
+    "tgis_clear_error": (None, []),
     "tgis_last_error": (ctypes.c_char_p, []),
     "tgis_device_info": (_c_int, [_c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64), ctypes.c_char_p, _c_int]),
     "tgis_timing_enable": (_c_int, [_c_int]),
@@ -314,6 +315,11 @@ def dense_gemm_partial(x: torch.Tensor, w: DenseWeight, bias=None, act: int = 0)
     p = Partial(slabs, S.value, ld.value, x.shape[0], w.N, bias)
     p.dtype = w.dtype
     return p
+
+
+def clear_error() -> None:
+    """Drop a stale HIP error (aborted graph capture) so that it is not blamed on the next launch."""
+    load_library().tgis_clear_error()
 
 
 # ---- norms --------------------------------------------------------------------------------------------
