@@ -14,26 +14,10 @@
 #include <stdlib.h>
 #include <algorithm>
 #include "common.h"
+#include "attention_args.h"
 
 namespace {
 
-struct AttnArgs {
-    const void* q;
-    int64_t ld_q;
-    const void* kpool;
-    const void* vpool;
-    const int32_t* bt;
-    int64_t max_pages;
-    const int32_t* ctx_lens;
-    const int32_t* cu_q;
-    void* out;
-    int H, Hkv, G, Gc, Gp, TQ, HC, NS;
-    float scale_log2;
-    float* ws_o;   // [total_q][H][NS][D]
-    float* ws_ml;  // [total_q][H][NS][2]
-};
-
-constexpr float NEG_BIG = -1.0e30f;
 
 // NW = waves per workgroup (the key range of a block is dealt page-by-page to its waves)
 template <typename T, int D, int NW>
@@ -322,6 +306,11 @@ extern "C" int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, 
                        (long)workspace_bytes, (long)need);
         a.ws_o = (float*)workspace;
         a.ws_ml = a.ws_o + total_q * H * num_splits * D;
+    }
+    // long q (prefill): blocks of 128 columns that stage each K/V page once in LDS (attention_prefill.hip)
+    if (num_splits == 1 && max_q_len * g.Gp > 64 && !getenv("TGIS_ATTN_NO_PREFILL_KERNEL")) {
+        TgisTimedScope timed(TGIS_OP_ATTN, st);
+        return tgis_launch_attn_prefill(a, B, Hkv, D, max_q_len, dtype, st);
     }
     int64_t q_tiles = cdiv64(max_q_len, g.TQ);
     TGIS_CHECK_ARG(q_tiles <= 2147483647LL && (int64_t)Hkv * g.HC <= 65535 && B * num_splits <= 65535,

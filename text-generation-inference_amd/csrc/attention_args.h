@@ -1,0 +1,24 @@
+// Shared by attention.hip (decode / short q) and attention_prefill.hip (long q): launch arguments and geometry.
+#pragma once
+#include "common.h"
+
+struct AttnArgs {
+    const void* q;
+    int64_t ld_q;
+    const void* kpool;
+    const void* vpool;
+    const int32_t* bt;
+    int64_t max_pages;
+    const int32_t* ctx_lens;
+    const int32_t* cu_q;
+    void* out;
+    int H, Hkv, G, Gc, Gp, TQ, HC, NS;
+    float scale_log2;
+    float* ws_o;   // [total_q][H][NS][D]
+    float* ws_ml;  // [total_q][H][NS][2]
+};
+
+constexpr float NEG_BIG = -1.0e30f;
+
+// prefill kernel launcher (attention_prefill.hip); `a` carries the geometry filled in by tgis_attn_paged
+int tgis_launch_attn_prefill(const AttnArgs& a, int64_t B, int Hkv, int D, int64_t max_q_len, int dtype, hipStream_t st);
