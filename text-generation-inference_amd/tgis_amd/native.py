@@ -182,6 +182,7 @@ class GptqWeight:
 
     def __init__(self, qweight, qzeros, scales, g_idx, bits: int, groupsize: int, gate_up: bool = False):
         self.flags = 1 if gate_up else 0
+        self.partial_plan = None  # (slab bytes, S, ld) of the deferred-reduce form, filled on first use
         if bits != 4:
             raise TgisHipError("only 4-bit GPTQ is supported (exllamav2.py:105)")
         lib = load_library()
@@ -253,15 +254,25 @@ def gptq_gemm_partial(x: torch.Tensor, w: GptqWeight, bias=None, act: int = 0) -
     """Launch the GEMM but leave the split-K reduce (and bias) to the consumer.  M <= 32."""
     assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] <= 32
     lib = load_library()
-    nbytes = lib.tgis_gptq_gemm_partial_bytes(w.K, w.N)
+    plan = w.partial_plan  # (slab bytes, S, ld): fixed per weight, asked from the library once
+    if plan is None:
+        nbytes = lib.tgis_gptq_gemm_partial_bytes(w.K, w.N)
+        slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        S = _c_int()
+        ld = _c_i64()
+        _check(
+            lib.tgis_gptq_gemm_f16_partial(_ptr(x), x.stride(0), _ptr(w.image), _ptr(w.perm), x.shape[0], w.K, w.N,
+                                           w.groups, act, _ptr(slabs), nbytes, ctypes.byref(S), ctypes.byref(ld),
+                                           _stream()), "tgis_gptq_gemm_f16_partial")
+        w.partial_plan = (nbytes, S.value, ld.value)
+        return Partial(slabs, S.value, ld.value, x.shape[0], w.N, bias)
+    nbytes, S, ld = plan
     slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-    S = _c_int()
-    ld = _c_i64()
     _check(
         lib.tgis_gptq_gemm_f16_partial(_ptr(x), x.stride(0), _ptr(w.image), _ptr(w.perm), x.shape[0], w.K, w.N,
-                                       w.groups, act, _ptr(slabs), nbytes, ctypes.byref(S), ctypes.byref(ld),
-                                       _stream()), "tgis_gptq_gemm_f16_partial")
-    return Partial(slabs, S.value, ld.value, x.shape[0], w.N, bias)
+                                       w.groups, act, _ptr(slabs), nbytes, None, None, _stream()),
+        "tgis_gptq_gemm_f16_partial")
+    return Partial(slabs, S, ld, x.shape[0], w.N, bias)
 
 
 def gptq_dequant(w: GptqWeight) -> torch.Tensor:
