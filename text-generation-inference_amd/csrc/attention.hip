@@ -318,7 +318,9 @@ extern "C" int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, 
     dim3 grid((unsigned)q_tiles, (unsigned)(Hkv * g.HC), (unsigned)(B * num_splits));
     // waves per block: with >= 1024 (sequence, kv head) blocks the chip is full either way and 2-wave blocks halve
     // the page-count imbalance between a block's waves (33 pages over 4 waves = 9/8/8/8; over 2 = 17/16)
-    int nw = (max_q_len == 1 && (int64_t)grid.x * grid.y * grid.z >= 1024) ? 2 : 4;
+    const int64_t nblocks = (int64_t)grid.x * grid.y * grid.z;
+    // (past ~2k blocks the dispatch rate, 7 ns per workgroup, costs more than the imbalance)
+    int nw = (max_q_len == 1 && nblocks >= 1024 && nblocks < 2048) ? 2 : 4;
     if (const char* e = getenv("TGIS_ATTN_NW")) nw = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 4;
     TgisTimedScope timed(TGIS_OP_ATTN, st);
     if (dtype == TGIS_F16) {

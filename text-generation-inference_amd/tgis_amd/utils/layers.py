@@ -17,8 +17,9 @@ from tgis_amd import native
 
 import os
 
-# rows up to which the weight-streaming MFMA kernels are used; above, dequant/hipBLASLt GEMM
-SKINNY_MAX_M = 64
+# rows up to which the weight-streaming MFMA kernels are used (one pass over the weights per 32 rows); above, dequant +
+# hipBLASLt.  Measured crossover on cfg3 shapes: ~13 us per 32-row slab vs ~170 us per GEMM for the dequant path.
+SKINNY_MAX_M = int(os.getenv("TGIS_SKINNY_MAX_M", "256"))
 # fuse the split-K reduce of decode-sized GPTQ GEMMs into the consumer kernel (rmsnorm / rope+KV write)
 DEFER_REDUCE = os.getenv("TGIS_DEFER_REDUCE", "true").lower() not in ("0", "false")
 
