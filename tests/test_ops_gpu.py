@@ -42,6 +42,9 @@ def _close(got, want, rtol, atol, what=""):
     (16, 1024, 256, 1024, False),      # per-channel (one group)
     (5, 1024, 128, 128, True),         # act-order g_idx
     (70, 2048, 2752, 128, False),      # TP-shard width (22016/8), M > 64
+    (40, 1024, 128, 128, True),        # act-order g_idx with a 64-row pass
+    (64, 4096, 4096, 128, False),      # one full 64-row pass
+    (100, 512, 96, 32, False),         # two 64-row passes, ragged, scale-in-weight path
     (5, 224, 64, 32, False),           # K % 64 == 32 (a regrouped row-parallel shard): half-valid last step
     (32, 1376, 4096, 32, False),       # llama-7B down_proj shard at tp=8 after regrouping 128 -> 32
     (32, 2752, 4096, 64, False),       # ... at tp=4 (groups of 64)

@@ -175,13 +175,18 @@ constexpr int RS = KC + 8;  // LDS row stride in halves (+16 B -> conflict-free 
 // counted vmcnt waits; everything wave-uniform lives in SGPRs.
 // GROUP64: group size is 64 * 2^n (one scale/zero per lane per step, prefetched with the weights).
 // TN = column tiles (waves) per k-part: 2, 3 or 4; WK = k-parts per block: 2 or 4 (plan_gemm).
-template <int TN, int WK, int ACT, bool GROUP64, bool PERM>
+// MR = 32-row blocks of x per pass: 1 (M <= 32), or 2 for larger decode batches — the wave dequantises each fragment
+// once and feeds it to two MFMAs, instead of streaming and dequantising the weights again for rows 32..63.  MR = 2 needs
+// WK = 2 (the x chunk buffers double).
+template <int TN, int WK, int ACT, bool GROUP64, bool PERM, int MR>
 __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
+    static_assert(MR == 1 || WK == 2, "64-row passes need the LDS of two k-parts");
+    constexpr int XR = 32 * MR;                 // x rows per pass
     // one chunk (4 one-KiB loads) of weights in flight per wave.  Measured: a two-chunk ring is ~1 us SLOWER on every
     // cfg3 shape (the first barrier waits for twice the prologue loads to issue; HBM is not the limiter afterwards)
     constexpr int RING = 4;
     constexpr int GT = 64 * TN;                 // threads of one k-part group
-    constexpr int NJ = (1024 + GT - 1) / GT;    // 16-byte x pieces per thread per chunk (32 rows x 32 pieces per chunk)
+    constexpr int NJ = (XR * 32 + GT - 1) / GT;  // 16-byte x pieces per thread per chunk (XR rows x 32 pieces per chunk)
     constexpr int RSTEP = GT / 32;              // rows covered by one pass of the group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -192,10 +197,10 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
     TRACE_RT(14);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = w % TN, wk = w / TN, ltid = wn * 64 + lane;
-    f16* xs = reinterpret_cast<f16*>(smem) + wk * (2 * 32 * RS);  // this k-part's [2][32][RS]
+    f16* xs = reinterpret_cast<f16*>(smem) + wk * (2 * XR * RS);  // this k-part's [2][XR][RS]
     const int ntg = blockIdx.x, split = blockIdx.y, mslab = blockIdx.z;
-    const int m0 = mslab * 32;
-    const int mrows = min(32, a.M - m0);
+    const int m0 = mslab * XR;
+    const int mrows = min(XR, a.M - m0);
     const int krp = a.KR / WK;                           // rows per k-part (multiple of 256)
     const int k0 = split * a.KR + wk * krp;
     const int k1 = min(a.K, k0 + krp);                   // may be <= k0 for trailing k-parts: they add zeros
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
         }
     };
     auto stage_store = [&](int buf) {
-        f16* dst = xs + buf * (32 * RS) + srow * RS + scol;
+        f16* dst = xs + buf * (XR * RS) + srow * RS + scol;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             f16x8 t = xg[j];
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
                     t[e] = (f16)((float)(f16)sl * (float)xu[j][e]);
                 }
             }
-            if (NJ * RSTEP == 32 || srow + RSTEP * j < 32) st16(dst + j * RSTEP * RS, t);
+            if (NJ * RSTEP == XR || srow + RSTEP * j < XR) st16(dst + j * RSTEP * RS, t);
         }
     };
 
@@ -280,9 +285,11 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
     asm volatile("" : "+v"(EXr));
     asm volatile("" : "+s"(M0r), "+s"(M1r));
     // two accumulators: consecutive MFMAs of a step alternate, halving the dependent-accumulator stalls
-    f32x16 accs[2];
+    f32x16 accs[MR][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) accs[i] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) accs[mr][i] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int xoff = (lane & 31) * RS + (lane >> 5) * 32;
 
     TRACE(1);
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
     // block-wide s_barrier would park every wave until the slowest of all TN*WK has finished its chunk (the SIMD
     // arbiter serves its oldest wave first, so a third of the loop time went to that skew).
     typedef __attribute__((address_space(3))) int lds_int;  // explicit LDS pointer: a generic one costs vmcnt(0) waits
-    volatile lds_int* sync_cnt = (volatile lds_int*)(smem + (size_t)WK * 2 * 32 * RS * sizeof(f16)) + wk;
+    volatile lds_int* sync_cnt = (volatile lds_int*)(smem + (size_t)WK * 2 * XR * RS * sizeof(f16)) + wk;
     if (wn == 0 && lane == 0) *sync_cnt = 0;
     // Issue order matters: a wave's loads return in order, so the (L2-resident) first x chunk goes out before the
     // HBM weight stream it would otherwise queue behind; then the small scale loads, then the ring of weights.
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
             for (int s4 = 0; s4 < 4; ++s4) szn[s4] = sz_at(chunk * 4 + s4 + RING);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const f16* xbuf = xs + (chunk & 1) * (32 * RS) + xoff;
+        const f16* xbuf = xs + (chunk & 1) * (XR * RS) + xoff;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const int step = chunk * 4 + s4;
@@ -373,12 +380,15 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #if defined(ABL_NOMFMA)
-                accs[i & 1][0] += (float)b[i][0] + (float)b[i][7];
+                accs[0][i & 1][0] += (float)b[i][0] + (float)b[i][7];
 #elif defined(ABL_NOLDSREAD)
-                accs[i & 1] = mfma32(b[(i + 1) & 3], b[i], accs[i & 1]);
+                accs[0][i & 1] = mfma32(b[(i + 1) & 3], b[i], accs[0][i & 1]);
 #else
-                f16x8 av = ld16<f16x8>(xk + i * 8);
-                accs[i & 1] = mfma32(av, b[i], accs[i & 1]);
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) {
+                    f16x8 av = ld16<f16x8>(xk + mr * (32 * RS) + i * 8);
+                    accs[mr][i & 1] = mfma32(av, b[i], accs[mr][i & 1]);
+                }
 #endif
             }
         }
@@ -400,35 +410,42 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every k-part is done with its x buffers: the reduction below reuses them
 
-    f32x16 acc = accs[0] + accs[1];
+    f32x16 acc[MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) acc[mr] = accs[mr][0] + accs[mr][1];
     // ---- sum the WK k-parts through LDS (fixed order => deterministic) --------------------------------
     if (WK > 1) {
-        float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][64 lanes][16]; the x buffers are dead now
+        float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][MR][64 lanes][16]; the x buffers are dead now
         if (wk > 0) {
-            float* dst = red + (((wk * TN + wn) * 64 + lane) << 4);
 #pragma unroll
-            for (int r = 0; r < 16; r += 4)
-                *reinterpret_cast<f32x4*>(dst + r) = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
+            for (int mr = 0; mr < MR; ++mr) {
+                float* dst = red + ((((wk * TN + wn) * MR + mr) * 64 + lane) << 4);
+#pragma unroll
+                for (int r = 0; r < 16; r += 4)
+                    *reinterpret_cast<f32x4*>(dst + r) = f32x4{acc[mr][r], acc[mr][r + 1], acc[mr][r + 2], acc[mr][r + 3]};
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         TRACE(11);
         if (wk > 0) return;
 #pragma unroll
-        for (int k2 = 1; k2 < WK; ++k2) {
-            const float* src = red + (((k2 * TN + wn) * 64 + lane) << 4);
+        for (int k2 = 1; k2 < WK; ++k2)
 #pragma unroll
-            for (int r = 0; r < 16; r += 4) {
-                f32x4 t = *reinterpret_cast<const f32x4*>(src + r);
-                acc[r] += t[0];
-                acc[r + 1] += t[1];
-                acc[r + 2] += t[2];
-                acc[r + 3] += t[3];
+            for (int mr = 0; mr < MR; ++mr) {
+                const float* src = red + ((((k2 * TN + wn) * MR + mr) * 64 + lane) << 4);
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                    f32x4 t = *reinterpret_cast<const f32x4*>(src + r);
+                    acc[mr][r] += t[0];
+                    acc[mr][r + 1] += t[1];
+                    acc[mr][r + 2] += t[2];
+                    acc[mr][r + 3] += t[3];
+                }
             }
-        }
     }
 
-    // ---- epilogue: lane holds out[m = (r&3)+8(r>>2)+4(lane>>5)][n = nt*32 + (lane&31)] ------------
+    // ---- epilogue: lane holds out[m = 32 mr + (r&3)+8(r>>2)+4(lane>>5)][n = nt*32 + (lane&31)] -------
     TRACE(12);
     TRACE_RT(15);
     if (nt_raw >= a.NT) return;
@@ -443,32 +460,40 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
         const int nsrc = (c < 16) ? j : half + j;
         const float bv = (a.bias && j < half) ? (float)a.bias[nsrc] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float mine = (float)(f16)(acc[r] + bv);
-            const float other = __shfl_xor(mine, 16, 64);
-            int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (c < 16 && j < half && m < mrows) {
-                float sl = mine / (1.f + __expf(-mine));
-                a.out[(int64_t)(m0 + m) * a.ldo + j] = (f16)((float)(f16)sl * other);
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float mine = (float)(f16)(acc[mr][r] + bv);
+                const float other = __shfl_xor(mine, 16, 64);
+                const int m = mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (c < 16 && j < half && m < mrows) {
+                    float sl = mine / (1.f + __expf(-mine));
+                    a.out[(int64_t)(m0 + m) * a.ldo + j] = (f16)((float)(f16)sl * other);
+                }
             }
-        }
         return;
     }
     if (a.S == 1 && !a.partial) {
         const float bv = (a.bias && n < a.N) ? (float)a.bias[n] : 0.f;
         if (n < a.N) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < mrows) a.out[(int64_t)(m0 + m) * a.ldo + n] = (f16)(acc[r] + bv);
-            }
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < mrows) a.out[(int64_t)(m0 + m) * a.ldo + n] = (f16)(acc[mr][r] + bv);
+                }
         }
     } else {
-        float* sl = a.slabs + ((int64_t)(mslab * a.S + split) * 32) * (a.NT * 32) + n;
+        // slabs are indexed in 32-row units: this pass owns units mslab*MR .. mslab*MR + MR-1
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            sl[(int64_t)m * (a.NT * 32)] = acc[r];
+        for (int mr = 0; mr < MR; ++mr) {
+            float* sl = a.slabs + ((int64_t)((mslab * MR + mr) * a.S + split) * 32) * (a.NT * 32) + n;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                sl[(int64_t)m * (a.NT * 32)] = acc[mr][r];
+            }
         }
     }
 }
@@ -523,19 +548,21 @@ __global__ void gptq_dequant_kernel(const uint8_t* __restrict__ prep, int64_t of
 
 struct GemmPlan {
     int KR, S, WK, TN;  // rows per block, global k splits, in-block k-parts, column tiles per k-part
+    int MR;             // 32-row blocks of x per pass (2 for M > 32)
 };
 
 // Block = 32*TN columns x KR rows, TN*WK waves (KR a multiple of 256*WK).  Measured on MI355X
 // (profiles/r01_gemm_pmc.md): weight streaming alone runs at ~3.3 TB/s for these sizes and dequant + MFMA add on
 // top rather than hide, so the plan first spreads the matrix over all 256 CUs (narrow blocks before global
 // k-splits, which cost slab traffic), then adds in-block k-parts (free of slab traffic) for waves per SIMD.
-static GemmPlan plan_gemm(int64_t K, int64_t N, int act = 0) {
+static GemmPlan plan_gemm(int64_t K, int64_t N, int act = 0, int64_t M = 32) {
+    const int MR = M > 32 ? 2 : 1;
     if (const char* ov = getenv("TGIS_GPTQ_PLAN")) {  // tuning hook: "KR,S,WK,TN"
         int kr = 0, sp = 0, wk = 0, tn = 0;
         if (sscanf(ov, "%d,%d,%d,%d", &kr, &sp, &wk, &tn) == 4 && kr > 0 && (wk == 2 || wk == 4) &&
             (tn >= 2 && tn <= 4) && kr % (KC * wk) == 0 && (int64_t)sp * kr >= K &&
-            (int64_t)(sp - 1) * kr < K && (act != 2 || sp == 1))
-            return {kr, sp, wk, tn};
+            (int64_t)(sp - 1) * kr < K && (act != 2 || sp == 1) && (MR == 1 || wk == 2))
+            return {kr, sp, wk, tn, MR};
     }
     const int64_t tiles = cdiv64(N, 32);
     const int64_t kchunks = cdiv64(K, KC);
@@ -544,9 +571,19 @@ static GemmPlan plan_gemm(int64_t K, int64_t N, int act = 0) {
     //    12 waves while they fit one per CU (gate_up 4096x22016: 230 blocks, 17.3 us vs 19.2 for 128-column blocks);
     //  medium N: 128-column blocks of two k-parts, split K until ~224 blocks (qkv 4096x12288: 10.8 vs 12.6 us);
     //  narrow N: 64-column blocks of four k-parts, split K until 256 blocks.
+    //  M > 32 (MR = 2): the x chunk buffers double, so two k-parts per block; 128-column blocks unless N is narrow,
+    //    and fewer global splits when several 64-row passes already multiply the blocks.
     int TN, WK;
     int64_t S = 1;
-    if (act == 2 || tiles >= 512) {
+    if (MR == 2) {
+        TN = tiles >= 256 ? 4 : 2;
+        WK = 2;
+        if (act != 2) {
+            const int64_t colblocks = cdiv64(tiles, TN) * cdiv64(M, 64);
+            S = std::max<int64_t>(1, std::min<int64_t>(kchunks / 2, (224 + colblocks / 2) / colblocks));
+            while (S > 1 && (S - 1) * cdiv64(kchunks, S) >= kchunks) --S;
+        }
+    } else if (act == 2 || tiles >= 512) {
         TN = cdiv64(tiles, 3) <= 256 ? 3 : 4;
         WK = 4;
     } else {
@@ -561,11 +598,12 @@ static GemmPlan plan_gemm(int64_t K, int64_t N, int act = 0) {
     if (KRc < WK) WK = 2;
     KRc = cdiv64(KRc, WK) * WK;  // whole chunks per k-part (rows beyond K contribute zeros)
     while (S > 1 && (S - 1) * KRc >= kchunks) --S;
-    return {(int)(KRc * KC), (int)S, WK, TN};
+    return {(int)(KRc * KC), (int)S, WK, TN, MR};
 }
 
+// slabs are stored in 32-row units; a 64-row pass always writes both of its units
 static int64_t slab_bytes(int64_t M, int64_t N, int S) {
-    return S > 1 ? cdiv64(M, 32) * S * 32 * cdiv64(N, 32) * 32 * 4 : 0;
+    return S > 1 ? cdiv64(M, 64) * 2 * S * 32 * cdiv64(N, 32) * 32 * 4 : 0;
 }
 
 }  // namespace
@@ -620,27 +658,34 @@ extern "C" int tgis_gptq_prepare(const int32_t* qweight, const int32_t* qzeros, 
 }
 
 extern "C" int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N) {
-    GemmPlan pl = plan_gemm(K, N);
+    GemmPlan pl = plan_gemm(K, N, 0, M);
     return 4096 + slab_bytes(M, N, pl.S);
 }
 
-template <int TN, int WK, int ACT, bool G64, bool PERM>
-static int launch_variant(dim3 grid, size_t lds, hipStream_t st, const GemmArgs& a) {
+template <int TN, int WK, int ACT, bool G64, bool PERM, int MR>
+static int launch_one(dim3 grid, size_t lds, hipStream_t st, const GemmArgs& a) {
     static bool attr_done = false;
     if (!attr_done) {
-        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_gemm_kernel<TN, WK, ACT, G64, PERM>,
+        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_gemm_kernel<TN, WK, ACT, G64, PERM, MR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * RS * 2 + 64));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gptq_gemm_kernel<TN, WK, ACT, G64, PERM>), grid, dim3(64 * TN * WK), lds, st, a);
+    hipLaunchKernelGGL((gptq_gemm_kernel<TN, WK, ACT, G64, PERM, MR>), grid, dim3(64 * TN * WK), lds, st, a);
     return TGIS_OK;
+}
+template <int TN, int WK, int ACT, bool G64, bool PERM>
+static int launch_variant(int mr, dim3 grid, size_t lds, hipStream_t st, const GemmArgs& a) {
+    if constexpr (WK == 2) {  // 64-row passes exist for two-k-part blocks only (LDS)
+        if (mr == 2) return launch_one<TN, WK, ACT, G64, PERM, 2>(grid, lds, st, a);
+    }
+    return launch_one<TN, WK, ACT, G64, PERM, 1>(grid, lds, st, a);
 }
 
 static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const void* bias, const int32_t* perm,
                        void* out, int64_t ldo, int64_t M, int64_t K, int64_t N, int64_t groups, int act, float* slabs,
                        int partial, const GemmPlan& pl, hipStream_t st) {
     PrepLayout p = prep_layout(K, N, groups);
-    const int64_t mslabs = cdiv64(M, 32);
+    const int64_t mslabs = cdiv64(M, 32 * pl.MR);  // passes over the weights
     const int64_t gs = K / groups;
     const int64_t spg = gs / 64;  // k64-steps per group
     const bool group64 = groups == 1 || (gs % 64 == 0 && (spg & (spg - 1)) == 0);
@@ -668,10 +713,10 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
     if (groups > 1 && group64)
         for (a.spg_shift = 0; (1 << a.spg_shift) < spg; ++a.spg_shift) {}
     dim3 grid((unsigned)cdiv64(p.NT, pl.TN), (unsigned)pl.S, (unsigned)mslabs);
-    const size_t lds = (size_t)pl.WK * 2 * 32 * RS * sizeof(f16) + 64;  // x buffers + arrival counters
+    const size_t lds = (size_t)pl.WK * 2 * 32 * pl.MR * RS * sizeof(f16) + 64;  // x buffers + arrival counters
 #define TGIS_LAUNCH_GEMM(T, W, A, G, P)                                                        \
     do {                                                                                       \
-        int rc_ = launch_variant<T, W, A, G, P>(grid, lds, st, a);                        \
+        int rc_ = launch_variant<T, W, A, G, P>(pl.MR, grid, lds, st, a);                      \
         if (rc_ != TGIS_OK) return rc_;                                                        \
     } while (0)
 #define TGIS_LAUNCH_GEMM_W(A, G, P)                      \
@@ -710,7 +755,7 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
     TGIS_CHECK_LAUNCH();
     if (!partial && pl.S > 1 && !getenv("TGIS_GPTQ_NOREDUCE")) {
         const int NP = (int)p.NT * 32;
-        dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 4), 256), (unsigned)mslabs);
+        dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 4), 256), (unsigned)cdiv64(M, 32));
         hipLaunchKernelGGL(splitk_reduce_f16_kernel, rgrid, dim3(256), 0, st, a.slabs, a.bias, a.out, a.ldo, a.M, a.N,
                            NP, a.S);
         TGIS_CHECK_LAUNCH();
@@ -738,7 +783,7 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
     TGIS_CHECK_ARG(out, "tgis_gptq_gemm_f16: null out");
     if (M == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
-    GemmPlan pl = plan_gemm(K, N, act);
+    GemmPlan pl = plan_gemm(K, N, act, M);
     TGIS_CHECK_ARG(cdiv64(M, 32) <= 65535, "tgis_gptq_gemm_f16: M too large for one launch");
     int64_t need = 4096 + slab_bytes(M, N, pl.S);
     TGIS_CHECK_ARG(workspace && workspace_bytes >= need, "tgis_gptq_gemm_f16: workspace too small (%ld < %ld)",
@@ -783,13 +828,13 @@ extern "C" int tgis_debug_gemm_occupancy(int tn, int wk) {
     int nb = -1;
     const size_t lds = (size_t)wk * 2 * 32 * RS * sizeof(f16) + 64;
     if (tn == 4 && wk == 4)
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<4, 4, 0, true, false>, 1024, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<4, 4, 0, true, false, 1>, 1024, lds);
     else if (tn == 2 && wk == 4)
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<2, 4, 0, true, false>, 512, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<2, 4, 0, true, false, 1>, 512, lds);
     else if (tn == 2 && wk == 2)
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<2, 2, 0, true, false>, 256, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<2, 2, 0, true, false, 1>, 256, lds);
     else if (tn == 3 && wk == 4)
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<3, 4, 0, true, false>, 768, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gptq_gemm_kernel<3, 4, 0, true, false, 1>, 768, lds);
     return nb;
 }
 
