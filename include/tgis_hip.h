@@ -98,12 +98,12 @@ int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepared, const v
                        const int32_t* perm, void* out, int64_t ldo, int64_t M, int64_t K, int64_t N,
                        int64_t groups, int act, void* workspace, int64_t workspace_bytes, void* stream);
 
-/* Deferred-reduce variant for M <= 32: instead of the f16 result, the S split-K partial sums are left in
- * `slabs` as fp32 [S][32][ld] (ld = N rounded up to 32, returned in *slab_ld; S in *num_slabs, >= 1) for a
+/* Deferred-reduce variant: instead of the f16 result, the S split-K partial sums are left in
+ * `slabs` as fp32 [ceil(M/32)][S][32][ld] (ld = N rounded up to 32, returned in *slab_ld; S in *num_slabs, >= 1) for a
  * consumer that sums them in its prologue (tgis_rmsnorm_residual_partial / tgis_rope_kv_write_partial), which
  * removes the reduce launch.  The consumer rounds the sum (+bias) to f16 first, so results are bit-identical to
- * tgis_gptq_gemm_f16 followed by the plain consumer.  slabs must hold tgis_gptq_gemm_partial_bytes(K,N) bytes. */
-int64_t tgis_gptq_gemm_partial_bytes(int64_t K, int64_t N);
+ * tgis_gptq_gemm_f16 followed by the plain consumer.  slabs must hold tgis_gptq_gemm_partial_bytes(M,K,N) bytes. */
+int64_t tgis_gptq_gemm_partial_bytes(int64_t M, int64_t K, int64_t N);
 int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void* prepared, const int32_t* perm, int64_t M,
                                int64_t K, int64_t N, int64_t groups, int act, float* slabs, int64_t slabs_bytes,
                                int* num_slabs, int64_t* slab_ld, void* stream);
@@ -123,9 +123,9 @@ int64_t tgis_dense_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
 int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared, const void* bias, void* out,
                     int64_t ldo, int64_t M, int64_t K, int64_t N, int dtype, int out_f32, int act,
                     void* workspace, int64_t workspace_bytes, void* stream);
-/* Deferred split-K for M <= 32, as tgis_gptq_gemm_f16_partial: the fp32 partial sums [num_slabs][32][slab_ld] are
+/* Deferred split-K, as tgis_gptq_gemm_f16_partial: the fp32 partial sums [ceil(M/32)][num_slabs][32][slab_ld] are
  * left for the consumer kernel (tgis_rmsnorm_residual_partial / tgis_rope_kv_write_partial), which adds the bias. */
-int64_t tgis_dense_gemm_partial_bytes(int64_t K, int64_t N);
+int64_t tgis_dense_gemm_partial_bytes(int64_t M, int64_t K, int64_t N);
 int tgis_dense_gemm_partial(const void* x, int64_t ldx, const void* prepared, int64_t M, int64_t K, int64_t N,
                             int dtype, int act, float* slabs, int64_t slabs_bytes, int* num_slabs,
                             int64_t* slab_ld, void* stream);
@@ -157,7 +157,7 @@ int tgis_rope_kv_write(void* qkv, int64_t ld_qkv, const void* cos, const void* s
                        const int32_t* positions, const int32_t* slots, void* k_pool, void* v_pool,
                        int64_t T, int H, int Hkv, int D, int rot_dim, int dtype, void* stream);
 
-/* Same with the qkv activation given as split-K partial sums (T <= 32): qkv_out[T, ld_qkv] receives
+/* Same with the qkv activation given as split-K partial sums: qkv_out[T, ld_qkv] receives
  * f16(sum_s slabs[s] (+ bias)) with q,k rotated; k,v go to the cache. */
 int tgis_rope_kv_write_partial(const float* slabs, int num_slabs, int64_t slab_ld, const void* bias, void* qkv_out,
                                int64_t ld_qkv, const void* cos, const void* sin, const int32_t* positions,

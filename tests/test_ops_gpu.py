@@ -295,7 +295,8 @@ def test_argmax_logprob(nat, gpu_device, dtype):
 
 
 # ---- deferred split-K reduce: GEMM leaves fp32 slabs, the consumer kernel finishes the sum -----------------------
-@pytest.mark.parametrize("M,K,N", [(32, 4096, 4096), (5, 11008, 4096), (1, 256, 64)])
+@pytest.mark.parametrize("M,K,N", [(32, 4096, 4096), (5, 11008, 4096), (1, 256, 64), (64, 4096, 4096), (40, 11008, 4096),
+                                   (100, 4096, 4096)])
 def test_gptq_partial_then_rmsnorm_is_bit_identical_to_unfused(nat, gpu_device, M, K, N):
     gs = 128 if K % 128 == 0 else 64
     qw, qz, sc, gi = ops_ref.make_gptq_tensors(K, N, gs, seed=K + N)

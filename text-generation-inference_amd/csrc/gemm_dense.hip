@@ -423,9 +423,9 @@ extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared,
                              : launch_dense<bf16>(a, pl, act, cdiv64(M, 32), st);
 }
 
-extern "C" int64_t tgis_dense_gemm_partial_bytes(int64_t K, int64_t N) {
+extern "C" int64_t tgis_dense_gemm_partial_bytes(int64_t M, int64_t K, int64_t N) {
     DensePlan pl = plan_dense(K, N);
-    return dense_slab_bytes(32, N, pl.S);
+    return dense_slab_bytes(std::max<int64_t>(M, 1), N, pl.S);
 }
 
 extern "C" int tgis_dense_gemm_partial(const void* x, int64_t ldx, const void* prepared, int64_t M, int64_t K,
@@ -433,8 +433,8 @@ extern "C" int tgis_dense_gemm_partial(const void* x, int64_t ldx, const void* p
                                        int* num_slabs, int64_t* slab_ld, void* stream) {
     int rc = dense_check(x, ldx, prepared, M, K, N, dtype, act);
     if (rc != TGIS_OK) return rc;
-    TGIS_CHECK_ARG(M >= 1 && M <= 32, "tgis_dense_gemm_partial: M must be in 1..32");
-    TGIS_CHECK_ARG(slabs && slabs_bytes >= tgis_dense_gemm_partial_bytes(K, N),
+    TGIS_CHECK_ARG(M >= 1 && cdiv64(M, 32) <= 65535, "tgis_dense_gemm_partial: bad M");
+    TGIS_CHECK_ARG(slabs && slabs_bytes >= tgis_dense_gemm_partial_bytes(M, K, N),
                    "tgis_dense_gemm_partial: slab buffer too small");
     hipStream_t st = (hipStream_t)stream;
     DensePlan pl = plan_dense(K, N);
@@ -443,5 +443,6 @@ extern "C" int tgis_dense_gemm_partial(const void* x, int64_t ldx, const void* p
     TgisTimedScope timed(TGIS_OP_DENSE_GEMM, st);
     DenseArgs a;
     dense_fill(a, x, ldx, prepared, nullptr, nullptr, 0, M, K, N, 0, slabs, 1, pl);
-    return dtype == TGIS_F16 ? launch_dense<f16>(a, pl, act, 1, st) : launch_dense<bf16>(a, pl, act, 1, st);
+    return dtype == TGIS_F16 ? launch_dense<f16>(a, pl, act, cdiv64(M, 32), st)
+                             : launch_dense<bf16>(a, pl, act, cdiv64(M, 32), st);
 }

@@ -793,9 +793,9 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
                        (float*)((uint8_t*)workspace + 4096), 0, pl, st);
 }
 
-extern "C" int64_t tgis_gptq_gemm_partial_bytes(int64_t K, int64_t N) {
-    GemmPlan pl = plan_gemm(K, N);
-    return (int64_t)pl.S * 32 * cdiv64(N, 32) * 32 * 4;
+extern "C" int64_t tgis_gptq_gemm_partial_bytes(int64_t M, int64_t K, int64_t N) {
+    GemmPlan pl = plan_gemm(K, N, 0, M);
+    return cdiv64(std::max<int64_t>(M, 1), 64) * 2 * pl.S * 32 * cdiv64(N, 32) * 32 * 4;
 }
 
 extern "C" int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void* prepared, const int32_t* perm,
@@ -803,10 +803,10 @@ extern "C" int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void
                                           int64_t slabs_bytes, int* num_slabs, int64_t* slab_ld, void* stream) {
     int rc = check_gemm_args(x, ldx, prepared, M, K, N, groups, act);
     if (rc != TGIS_OK) return rc;
-    TGIS_CHECK_ARG(M >= 1 && M <= 32, "tgis_gptq_gemm_f16_partial: M must be in 1..32");
+    TGIS_CHECK_ARG(M >= 1 && cdiv64(M, 32) <= 65535, "tgis_gptq_gemm_f16_partial: bad M");
     TGIS_CHECK_ARG(act != 2, "tgis_gptq_gemm_f16_partial: act=2 cannot be deferred");
-    GemmPlan pl = plan_gemm(K, N);
-    TGIS_CHECK_ARG(slabs && slabs_bytes >= tgis_gptq_gemm_partial_bytes(K, N),
+    GemmPlan pl = plan_gemm(K, N, 0, M);
+    TGIS_CHECK_ARG(slabs && slabs_bytes >= tgis_gptq_gemm_partial_bytes(M, K, N),
                    "tgis_gptq_gemm_f16_partial: slab buffer too small");
     hipStream_t st = (hipStream_t)stream;
     if (num_slabs) *num_slabs = pl.S;

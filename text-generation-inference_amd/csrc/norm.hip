@@ -48,7 +48,8 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
             V8 a;
             if (PARTIAL) {
                 f32x4 lo, hi;
-                sum_slabs8(slabs + row * slab_ld + c * 8, 32 * slab_ld, S, lo, hi);
+                // slabs are stored in 32-row units: [row / 32][S][32][slab_ld]
+                sum_slabs8(slabs + ((int64_t)(row >> 5) * S * 32 + (row & 31)) * slab_ld + c * 8, 32 * slab_ld, S, lo, hi);
                 if (xbias) {
                     V8 bv = ld16<V8>(xbias + c * 8);
 #pragma unroll
@@ -129,8 +130,8 @@ static int launch_norm(const void* x, const void* residual, const void* weight, 
                        void* res_out, int64_t rows, int64_t hidden, float eps, int dtype, void* stream,
                        const float* slabs = nullptr, int S = 0, int64_t slab_ld = 0, const void* xbias = nullptr) {
     TGIS_CHECK_ARG((x || slabs) && weight && y, "norm: null tensor");
-    TGIS_CHECK_ARG(!slabs || (rows <= 32 && S >= 1 && slab_ld >= hidden && slab_ld % 4 == 0),
-                   "norm: partial input needs rows <= 32 and a slab row stride >= hidden");
+    TGIS_CHECK_ARG(!slabs || (S >= 1 && slab_ld >= hidden && slab_ld % 4 == 0),
+                   "norm: partial input needs a slab row stride >= hidden");
     TGIS_CHECK_ARG(hidden > 0 && hidden % 8 == 0 && hidden <= MAX_HIDDEN,
                    "norm: hidden (%ld) must be a multiple of 8 and <= %d", (long)hidden, MAX_HIDDEN);
     TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "norm: bad dtype");

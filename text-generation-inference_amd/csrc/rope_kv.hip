@@ -32,7 +32,7 @@ __device__ __forceinline__ typename VecT<T>::x8 load_chunk(const T* hp, int64_t 
     using V8 = typename VecT<T>::x8;
     if (pin.slabs == nullptr) return ld16<V8>(hp);
     f32x4 lo, hi;
-    sum_slabs8(pin.slabs + t * pin.slab_ld + col, 32 * pin.slab_ld, pin.S, lo, hi);
+    sum_slabs8(pin.slabs + ((t >> 5) * pin.S * 32 + (t & 31)) * pin.slab_ld + col, 32 * pin.slab_ld, pin.S, lo, hi);
     V8 a;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -196,8 +196,8 @@ static int rope_launch(void* qkv, int64_t ld_qkv, const void* cos, const void* s
                    "tgis_rope_kv_write: rot_dim must be a multiple of 16 and <= head_dim");
     TGIS_CHECK_ARG((!k_pool && !v_pool) || slots, "tgis_rope_kv_write: cache write needs slots");
     TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "tgis_rope_kv_write: bad dtype");
-    TGIS_CHECK_ARG(!slabs || (T <= 32 && S >= 1 && slab_ld >= (int64_t)(H + 2 * Hkv) * D && slab_ld % 4 == 0),
-                   "tgis_rope_kv_write_partial: needs T <= 32 and a slab row stride >= (H + 2 Hkv) D");
+    TGIS_CHECK_ARG(!slabs || (S >= 1 && slab_ld >= (int64_t)(H + 2 * Hkv) * D && slab_ld % 4 == 0),
+                   "tgis_rope_kv_write_partial: needs a slab row stride >= (H + 2 Hkv) D");
     if (T == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
     TgisTimedScope timed(TGIS_OP_ROPE_KV, st);

@@ -40,7 +40,7 @@ SIGNATURES = {
     "tgis_gptq_gemm_workspace_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
     "tgis_gptq_gemm_f16": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64,
                                     _c_int, _vp, _c_i64, _vp]),
-    "tgis_gptq_gemm_partial_bytes": (_c_i64, [_c_i64, _c_i64]),
+    "tgis_gptq_gemm_partial_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
     "tgis_gptq_gemm_f16_partial": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_i64,
                                             ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64), _vp]),
     "tgis_gptq_dequant_f16": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp]),
@@ -49,7 +49,7 @@ SIGNATURES = {
     "tgis_dense_gemm_workspace_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
     "tgis_dense_gemm": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int,
                                  _c_int, _vp, _c_i64, _vp]),
-    "tgis_dense_gemm_partial_bytes": (_c_i64, [_c_i64, _c_i64]),
+    "tgis_dense_gemm_partial_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
     "tgis_dense_gemm_partial": (_c_int, [_vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _vp, _c_i64,
                                          ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64), _vp]),
     "tgis_rmsnorm_residual": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f, _c_int, _vp]),
@@ -182,7 +182,7 @@ class GptqWeight:
 
     def __init__(self, qweight, qzeros, scales, g_idx, bits: int, groupsize: int, gate_up: bool = False):
         self.flags = 1 if gate_up else 0
-        self.partial_plan = None  # (slab bytes, S, ld) of the deferred-reduce form, filled on first use
+        self.partial_plan = {}  # pass count -> (slab bytes, S, ld) of the deferred-reduce form, filled on first use
         if bits != 4:
             raise TgisHipError("only 4-bit GPTQ is supported (exllamav2.py:105)")
         lib = load_library()
@@ -237,7 +237,7 @@ def gptq_gemm(x: torch.Tensor, w: GptqWeight, ws: Workspace, bias=None, act: int
 
 
 class Partial:
-    """fp32 split-K partial sums [S, 32, ld] of a GEMM whose reduce is deferred to the consumer kernel
+    """fp32 split-K partial sums [ceil(M/32), S, 32, ld] of a GEMM whose reduce is deferred to the consumer kernel
     (rmsnorm_residual / rope_kv_write accept it in place of the f16 activation)."""
 
     def __init__(self, slabs: torch.Tensor, S: int, ld: int, M: int, N: int, bias):
@@ -250,29 +250,35 @@ class Partial:
         return (self.M, self.N)
 
 
+PARTIAL_MAX_M = 256  # rows up to which a GEMM may leave its split-K sum to the consumer kernel
+
+
 def gptq_gemm_partial(x: torch.Tensor, w: GptqWeight, bias=None, act: int = 0) -> Partial:
-    """Launch the GEMM but leave the split-K reduce (and bias) to the consumer.  M <= 32."""
-    assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] <= 32
+    """Launch the GEMM but leave the split-K reduce (and bias) to the consumer.  Slabs are stored in 32-row units:
+    [ceil(M/32)][S][32][ld]."""
+    assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] <= PARTIAL_MAX_M
     lib = load_library()
-    plan = w.partial_plan  # (slab bytes, S, ld): fixed per weight, asked from the library once
+    M = x.shape[0]
+    key = (M + 63) // 64 if M > 32 else 0  # the plan depends on M only through its pass count
+    plan = w.partial_plan.get(key)  # (slab bytes, S, ld): asked from the library once per weight and pass count
     if plan is None:
-        nbytes = lib.tgis_gptq_gemm_partial_bytes(w.K, w.N)
+        nbytes = lib.tgis_gptq_gemm_partial_bytes(M, w.K, w.N)
         slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
         S = _c_int()
         ld = _c_i64()
         _check(
-            lib.tgis_gptq_gemm_f16_partial(_ptr(x), x.stride(0), _ptr(w.image), _ptr(w.perm), x.shape[0], w.K, w.N,
+            lib.tgis_gptq_gemm_f16_partial(_ptr(x), x.stride(0), _ptr(w.image), _ptr(w.perm), M, w.K, w.N,
                                            w.groups, act, _ptr(slabs), nbytes, ctypes.byref(S), ctypes.byref(ld),
                                            _stream()), "tgis_gptq_gemm_f16_partial")
-        w.partial_plan = (nbytes, S.value, ld.value)
-        return Partial(slabs, S.value, ld.value, x.shape[0], w.N, bias)
+        w.partial_plan[key] = (nbytes, S.value, ld.value)
+        return Partial(slabs, S.value, ld.value, M, w.N, bias)
     nbytes, S, ld = plan
     slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     _check(
-        lib.tgis_gptq_gemm_f16_partial(_ptr(x), x.stride(0), _ptr(w.image), _ptr(w.perm), x.shape[0], w.K, w.N,
+        lib.tgis_gptq_gemm_f16_partial(_ptr(x), x.stride(0), _ptr(w.image), _ptr(w.perm), M, w.K, w.N,
                                        w.groups, act, _ptr(slabs), nbytes, None, None, _stream()),
         "tgis_gptq_gemm_f16_partial")
-    return Partial(slabs, S, ld, x.shape[0], w.N, bias)
+    return Partial(slabs, S, ld, M, w.N, bias)
 
 
 def gptq_dequant(w: GptqWeight) -> torch.Tensor:
@@ -319,10 +325,10 @@ def dense_gemm(x: torch.Tensor, w: DenseWeight, ws: Workspace, bias=None, out_f3
 
 
 def dense_gemm_partial(x: torch.Tensor, w: DenseWeight, bias=None, act: int = 0) -> Partial:
-    """Launch the dense GEMM but leave the split-K reduce (and bias) to the consumer kernel.  M <= 32."""
-    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == w.dtype and x.shape[0] <= 32
+    """Launch the dense GEMM but leave the split-K reduce (and bias) to the consumer kernel."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == w.dtype and x.shape[0] <= PARTIAL_MAX_M
     lib = load_library()
-    nbytes = lib.tgis_dense_gemm_partial_bytes(w.K, w.N)
+    nbytes = lib.tgis_dense_gemm_partial_bytes(x.shape[0], w.K, w.N)
     slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     S = _c_int()
     ld = _c_i64()

@@ -42,7 +42,7 @@ class FastLinear:
         self.out_features, self.in_features = weight.shape
 
     def forward(self, x: torch.Tensor, act: int = 0, out_f32: bool = False, partial: bool = False) -> torch.Tensor:
-        if partial and x.shape[0] <= 32 and DEFER_REDUCE and not out_f32:
+        if partial and x.shape[0] <= native.PARTIAL_MAX_M and DEFER_REDUCE and not out_f32:
             # the split-K sum (and the bias) is finished by the consumer kernel (add+norm / rope): no reduce launch
             return native.dense_gemm_partial(x, self.prepared, bias=self.bias, act=act)
         if x.shape[0] <= SKINNY_MAX_M:
@@ -98,7 +98,7 @@ class Ex4bitLinearV2:
             if x.shape[0] <= SKINNY_MAX_M:
                 return native.gptq_gemm(x, self.q_handle, workspace(x.device), bias=self.bias, act=2)
             return native.act_mul(self._large_m(x), self.width // 2)
-        if partial and x.shape[0] <= 32 and DEFER_REDUCE:
+        if partial and x.shape[0] <= native.PARTIAL_MAX_M and DEFER_REDUCE:
             return native.gptq_gemm_partial(x, self.q_handle, bias=self.bias, act=act)
         if x.shape[0] <= SKINNY_MAX_M:
             return native.gptq_gemm(x, self.q_handle, workspace(x.device), bias=self.bias, act=act)
