@@ -89,6 +89,7 @@ def test_gptq_gemm_fused_silu(nat, gpu_device):
 # ---- dense skinny GEMM -------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,K,N,f32out", [(32, 4096, 32000, True), (16, 2048, 2560, False), (3, 200, 72, False),
+                                          (64, 2048, 5632, False), (100, 1024, 160, True),
                                          (40, 512, 100, True)])
 def test_dense_gemm(nat, gpu_device, dtype, M, K, N, f32out):
     g = torch.Generator().manual_seed(M + K + N)
@@ -366,7 +367,7 @@ def test_gptq_gemm_gate_up_epilogue(nat, gpu_device, M, K, I):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,K,N", [(16, 2048, 2048), (32, 5632, 2048), (3, 256, 96)])
+@pytest.mark.parametrize("M,K,N", [(16, 2048, 2048), (32, 5632, 2048), (3, 256, 96), (64, 2048, 2048), (40, 5632, 2048)])
 def test_dense_partial_then_rmsnorm_is_bit_identical_to_unfused(nat, gpu_device, dtype, M, K, N):
     g = torch.Generator().manual_seed(M + K)
     w = (torch.randn(N, K, generator=g) * 0.02).to(dtype)

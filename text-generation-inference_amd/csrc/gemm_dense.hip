@@ -64,20 +64,24 @@ constexpr int DRING = 2;      // k64-steps of weights in flight per wave (2 x 4 
 // itself with an LDS arrival counter; k-parts are summed through LDS in fixed order; global k-splits leave fp32
 // slabs for the consumer kernel.  The image is zero-padded past K and N; x columns past the wave's k-range are
 // zeroed when the chunk is staged (the fragments there belong to the next k-part).
-template <typename T, int TN, int WK, int ACT>
+// MR = 32-row blocks of x per pass (2 for M > 32: every weight fragment then feeds two MFMAs instead of being streamed
+// again for rows 32..63; needs WK = 2 for the doubled x buffers).
+template <typename T, int TN, int WK, int ACT, int MR>
 __global__ __launch_bounds__(64 * TN * WK) void dense_gemm_kernel(DenseArgs a) {
+    static_assert(MR == 1 || WK == 2, "64-row passes need the LDS of two k-parts");
     using V8 = typename VecT<T>::x8;
+    constexpr int XR = 32 * MR;
     constexpr int GT = 64 * TN;
-    constexpr int NJ = (1024 + GT - 1) / GT;
+    constexpr int NJ = (XR * 32 + GT - 1) / GT;
     constexpr int RSTEP = GT / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = w % TN, wk = w / TN, ltid = wn * 64 + lane;
-    T* xs = reinterpret_cast<T*>(smem) + wk * (2 * 32 * DRS);
+    T* xs = reinterpret_cast<T*>(smem) + wk * (2 * XR * DRS);
     const int ntg = blockIdx.x, split = blockIdx.y, mslab = blockIdx.z;
-    const int m0 = mslab * 32;
-    const int mrows = min(32, a.M - m0);
+    const int m0 = mslab * XR;
+    const int mrows = min(XR, a.M - m0);
     const int krp = a.KR / WK;
     const int k0 = split * a.KR + wk * krp;
     const int k1 = min(a.K, k0 + krp);
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(64 * TN * WK) void dense_gemm_kernel(DenseArgs a) {
         }
     };
     auto stage_store = [&](int buf) {
-        T* dst = xs + buf * (32 * DRS) + srow * DRS + scol;
+        T* dst = xs + buf * (XR * DRS) + srow * DRS + scol;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             V8 t = xg[j];
@@ -138,17 +142,19 @@ __global__ __launch_bounds__(64 * TN * WK) void dense_gemm_kernel(DenseArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[e] = (T)0.f;
             }
-            if (NJ * RSTEP == 32 || srow + RSTEP * j < 32) st16(dst + j * RSTEP * DRS, t);
+            if (NJ * RSTEP == XR || srow + RSTEP * j < XR) st16(dst + j * RSTEP * DRS, t);
         }
     };
 
-    f32x16 accs[2];
+    f32x16 accs[MR][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) accs[i] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) accs[mr][i] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int xoff = (lane & 31) * DRS + (lane >> 5) * 32;
 
     typedef __attribute__((address_space(3))) int lds_int;
-    volatile lds_int* sync_cnt = (volatile lds_int*)(smem + (size_t)WK * 2 * 32 * DRS * sizeof(T)) + wk;
+    volatile lds_int* sync_cnt = (volatile lds_int*)(smem + (size_t)WK * 2 * XR * DRS * sizeof(T)) + wk;
     if (wn == 0 && lane == 0) *sync_cnt = 0;
     stage_load(0);  // x first: a wave's loads return in order and this one is L2-resident
 #pragma unroll
@@ -168,17 +174,19 @@ __global__ __launch_bounds__(64 * TN * WK) void dense_gemm_kernel(DenseArgs a) {
         constexpr bool LAST = decltype(last_tag)::value;
         if (!LAST) stage_load(chunk + 1);
         __builtin_amdgcn_sched_barrier(0);
-        const T* xbuf = xs + (chunk & 1) * (32 * DRS) + xoff;
+        const T* xbuf = xs + (chunk & 1) * (XR * DRS) + xoff;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const int step = chunk * 4 + s4;
             const T* xk = xbuf + s4 * 64;
             V8* cur = wq[s4 & (DRING - 1)];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                V8 av = ld16<V8>(xk + i * 8);
-                accs[i & 1] = mfma32(av, cur[i], accs[i & 1]);
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) {
+                    V8 av = ld16<V8>(xk + mr * (32 * DRS) + i * 8);
+                    accs[mr][i & 1] = mfma32(av, cur[i], accs[mr][i & 1]);
+                }
             // the slot is consumed: refill it in place, DRING steps ahead (the last chunk only refills what it
             // will still consume itself)
             if (!LAST || s4 + DRING < 4) {
@@ -196,53 +204,65 @@ __global__ __launch_bounds__(64 * TN * WK) void dense_gemm_kernel(DenseArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every k-part is done with its x buffers: the reduction below reuses them
 
-    f32x16 acc = accs[0] + accs[1];
-    if (WK > 1) {
-        float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][64 lanes][16]
-        if (wk > 0) {
-            float* dst = red + (((wk * TN + wn) * 64 + lane) << 4);
+    f32x16 acc[MR];
 #pragma unroll
-            for (int r = 0; r < 16; r += 4)
-                *reinterpret_cast<f32x4*>(dst + r) = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
+    for (int mr = 0; mr < MR; ++mr) acc[mr] = accs[mr][0] + accs[mr][1];
+    if (WK > 1) {
+        float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][MR][64 lanes][16]
+        if (wk > 0) {
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+                float* dst = red + ((((wk * TN + wn) * MR + mr) * 64 + lane) << 4);
+#pragma unroll
+                for (int r = 0; r < 16; r += 4)
+                    *reinterpret_cast<f32x4*>(dst + r) = f32x4{acc[mr][r], acc[mr][r + 1], acc[mr][r + 2], acc[mr][r + 3]};
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wk > 0) return;
 #pragma unroll
-        for (int k2 = 1; k2 < WK; ++k2) {
-            const float* src = red + (((k2 * TN + wn) * 64 + lane) << 4);
+        for (int k2 = 1; k2 < WK; ++k2)
 #pragma unroll
-            for (int r = 0; r < 16; r += 4) {
-                f32x4 t = *reinterpret_cast<const f32x4*>(src + r);
-                acc[r] += t[0];
-                acc[r + 1] += t[1];
-                acc[r + 2] += t[2];
-                acc[r + 3] += t[3];
+            for (int mr = 0; mr < MR; ++mr) {
+                const float* src = red + ((((k2 * TN + wn) * MR + mr) * 64 + lane) << 4);
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                    f32x4 t = *reinterpret_cast<const f32x4*>(src + r);
+                    acc[mr][r] += t[0];
+                    acc[mr][r + 1] += t[1];
+                    acc[mr][r + 2] += t[2];
+                    acc[mr][r + 3] += t[3];
+                }
             }
-        }
     }
 
-    // ---- epilogue: lane holds out[m = (r&3)+8(r>>2)+4(lane>>5)][n = nt*32 + (lane&31)] ------------
+    // ---- epilogue: lane holds out[m = 32 mr + (r&3)+8(r>>2)+4(lane>>5)][n = nt*32 + (lane&31)] -------
     if (nt_raw >= a.NT) return;
     const int n = nt * 32 + (lane & 31);
     if (a.S == 1 && !a.partial) {
         if (n >= a.N) return;
         const float bv = a.bias ? to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m >= mrows) continue;
-            if (a.out_f32)
-                reinterpret_cast<float*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = acc[r] + bv;
-            else
-                reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = from_f32<T>(acc[r] + bv);
-        }
-    } else {
-        float* sl = a.slabs + ((int64_t)(mslab * a.S + split) * 32) * (a.NT * 32) + n;
+        for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            sl[(int64_t)m * (a.NT * 32)] = acc[r];
+            for (int r = 0; r < 16; ++r) {
+                const int m = mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= mrows) continue;
+                if (a.out_f32)
+                    reinterpret_cast<float*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = acc[mr][r] + bv;
+                else
+                    reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = from_f32<T>(acc[mr][r] + bv);
+            }
+    } else {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            float* sl = a.slabs + ((int64_t)((mslab * MR + mr) * a.S + split) * 32) * (a.NT * 32) + n;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                sl[(int64_t)m * (a.NT * 32)] = acc[mr][r];
+            }
         }
     }
 }
@@ -274,16 +294,23 @@ __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float* _
 }
 
 struct DensePlan {
-    int KR, S, WK, TN;
+    int KR, S, WK, TN, MR;
 };
 
 // Same shape rules as plan_gemm (gptq.hip) — the bytes per tile are 4x, the block structure is the same.
-static DensePlan plan_dense(int64_t K, int64_t N) {
+static DensePlan plan_dense(int64_t K, int64_t N, int64_t M = 32) {
     const int64_t tiles = cdiv64(N, 32);
     const int64_t kchunks = cdiv64(K, DKC);
+    const int MR = M > 32 ? 2 : 1;
     int TN, WK;
     int64_t S = 1;
-    if (tiles >= 512) {
+    if (MR == 2) {
+        TN = tiles >= 256 ? 4 : 2;
+        WK = 2;
+        const int64_t colblocks = cdiv64(tiles, TN) * cdiv64(M, 64);
+        S = std::max<int64_t>(1, std::min<int64_t>(kchunks / 2, (224 + colblocks / 2) / colblocks));
+        while (S > 1 && (S - 1) * cdiv64(kchunks, S) >= kchunks) --S;
+    } else if (tiles >= 512) {
         TN = cdiv64(tiles, 3) <= 256 ? 3 : 4;
         WK = 4;
     } else {
@@ -298,31 +325,41 @@ static DensePlan plan_dense(int64_t K, int64_t N) {
     if (KRc < WK) WK = 2;
     KRc = cdiv64(KRc, WK) * WK;
     while (S > 1 && (S - 1) * KRc >= kchunks) --S;
-    return {(int)(KRc * DKC), (int)S, WK, TN};
+    return {(int)(KRc * DKC), (int)S, WK, TN, MR};
 }
 
-static int64_t dense_slab_bytes(int64_t M, int64_t N, int S) { return cdiv64(M, 32) * S * 32 * cdiv64(N, 32) * 32 * 4; }
+// slabs are stored in 32-row units; a 64-row pass always writes both of its units
+static int64_t dense_slab_bytes(int64_t M, int64_t N, int S) {
+    return cdiv64(M, 64) * 2 * S * 32 * cdiv64(N, 32) * 32 * 4;
+}
 
-template <typename T, int TN, int WK, int ACT>
-static int launch_dense_variant(dim3 grid, size_t lds, hipStream_t st, const DenseArgs& a) {
+template <typename T, int TN, int WK, int ACT, int MR>
+static int launch_dense_one(dim3 grid, size_t lds, hipStream_t st, const DenseArgs& a) {
     static bool attr = false;
     if (!attr) {
-        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)dense_gemm_kernel<T, TN, WK, ACT>,
+        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)dense_gemm_kernel<T, TN, WK, ACT, MR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * DRS * 2 + 64));
         attr = true;
     }
-    hipLaunchKernelGGL((dense_gemm_kernel<T, TN, WK, ACT>), grid, dim3(64 * TN * WK), lds, st, a);
+    hipLaunchKernelGGL((dense_gemm_kernel<T, TN, WK, ACT, MR>), grid, dim3(64 * TN * WK), lds, st, a);
     return TGIS_OK;
+}
+template <typename T, int TN, int WK, int ACT>
+static int launch_dense_variant(int mr, dim3 grid, size_t lds, hipStream_t st, const DenseArgs& a) {
+    if constexpr (WK == 2) {
+        if (mr == 2) return launch_dense_one<T, TN, WK, ACT, 2>(grid, lds, st, a);
+    }
+    return launch_dense_one<T, TN, WK, ACT, 1>(grid, lds, st, a);
 }
 
 template <typename T>
-static int launch_dense(const DenseArgs& a, const DensePlan& pl, int act, int64_t mslabs, hipStream_t st) {
-    dim3 grid((unsigned)cdiv64(a.NT, pl.TN), (unsigned)pl.S, (unsigned)mslabs);
-    const size_t lds = (size_t)pl.WK * 2 * 32 * DRS * sizeof(T) + 64;
+static int launch_dense(const DenseArgs& a, const DensePlan& pl, int act, int64_t mslabs32, hipStream_t st) {
+    dim3 grid((unsigned)cdiv64(a.NT, pl.TN), (unsigned)pl.S, (unsigned)cdiv64(mslabs32, pl.MR));
+    const size_t lds = (size_t)pl.WK * 2 * 32 * pl.MR * DRS * sizeof(T) + 64;
     int rc = TGIS_EINVAL;
 #define TGIS_DENSE_CASE(T_, W_)                                                        \
     if (pl.TN == T_ && pl.WK == W_)                                                    \
-        rc = act ? launch_dense_variant<T, T_, W_, 1>(grid, lds, st, a) : launch_dense_variant<T, T_, W_, 0>(grid, lds, st, a)
+        rc = act ? launch_dense_variant<T, T_, W_, 1>(pl.MR, grid, lds, st, a) : launch_dense_variant<T, T_, W_, 0>(pl.MR, grid, lds, st, a)
     TGIS_DENSE_CASE(2, 2);
     TGIS_DENSE_CASE(2, 4);
     TGIS_DENSE_CASE(3, 4);
@@ -336,7 +373,7 @@ static int launch_dense(const DenseArgs& a, const DensePlan& pl, int act, int64_
     TGIS_CHECK_LAUNCH();
     if (!a.partial && pl.S > 1) {
         const int NP = a.NT * 32;
-        dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 4), 256), (unsigned)mslabs);
+        dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 4), 256), (unsigned)mslabs32);
         hipLaunchKernelGGL(dense_splitk_reduce_kernel<T>, rgrid, dim3(256), 0, st, a.slabs, (const T*)a.bias, a.out, a.ldo,
                            a.M, a.N, NP, a.S, a.out_f32);
         TGIS_CHECK_LAUNCH();
@@ -368,7 +405,7 @@ extern "C" int tgis_dense_prepare(const void* w, int64_t N, int64_t K, int dtype
 }
 
 extern "C" int64_t tgis_dense_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N) {
-    DensePlan pl = plan_dense(K, N);
+    DensePlan pl = plan_dense(K, N, M);
     return 4096 + (pl.S > 1 ? dense_slab_bytes(M, N, pl.S) : 0);
 }
 
@@ -412,7 +449,7 @@ extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared,
     TGIS_CHECK_ARG(out, "tgis_dense_gemm: null out");
     if (M == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
-    DensePlan pl = plan_dense(K, N);
+    DensePlan pl = plan_dense(K, N, M);
     const int64_t need = tgis_dense_gemm_workspace_bytes(M, K, N);
     TGIS_CHECK_ARG(workspace && workspace_bytes >= need, "tgis_dense_gemm: workspace too small (%ld < %ld)",
                    (long)workspace_bytes, (long)need);
@@ -424,7 +461,7 @@ extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared,
 }
 
 extern "C" int64_t tgis_dense_gemm_partial_bytes(int64_t M, int64_t K, int64_t N) {
-    DensePlan pl = plan_dense(K, N);
+    DensePlan pl = plan_dense(K, N, M);
     return dense_slab_bytes(std::max<int64_t>(M, 1), N, pl.S);
 }
 
@@ -437,7 +474,7 @@ extern "C" int tgis_dense_gemm_partial(const void* x, int64_t ldx, const void* p
     TGIS_CHECK_ARG(slabs && slabs_bytes >= tgis_dense_gemm_partial_bytes(M, K, N),
                    "tgis_dense_gemm_partial: slab buffer too small");
     hipStream_t st = (hipStream_t)stream;
-    DensePlan pl = plan_dense(K, N);
+    DensePlan pl = plan_dense(K, N, M);
     if (num_slabs) *num_slabs = pl.S;
     if (slab_ld) *slab_ld = cdiv64(N, 32) * 32;
     TgisTimedScope timed(TGIS_OP_DENSE_GEMM, st);
