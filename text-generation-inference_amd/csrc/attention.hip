@@ -248,7 +248,9 @@ extern "C" int tgis_attn_num_splits(int64_t B, int Hkv, int H, int64_t max_q_len
     int64_t q_tiles = cdiv64(max_q_len, g.TQ);
     int64_t base = B * Hkv * g.HC * q_tiles;
     int64_t pages = cdiv64(std::max<int64_t>(max_ctx, 1), 32);
-    int64_t ns = cdiv64(1024, base);
+    // ~512 blocks: enough to fill 256 CUs twice; more, thinner blocks lose to the dispatch ramp and the combine pass
+    // (tools/split_sweep.py: B=32 MQA ctx 4096: 19 us at 8 splits vs 26 us at 32)
+    int64_t ns = cdiv64(512, base);
     ns = std::min<int64_t>(ns, cdiv64(pages, 4));  // at least one page per wave
     ns = std::max<int64_t>(1, std::min<int64_t>(ns, 64));
     return (int)ns;
