@@ -584,7 +584,9 @@ static GemmPlan plan_gemm(int64_t K, int64_t N, int act = 0, int64_t M = 32) {
             while (S > 1 && (S - 1) * cdiv64(kchunks, S) >= kchunks) --S;
         }
     } else if (act == 2 || tiles >= 512) {
-        TN = cdiv64(tiles, 3) <= 256 ? 3 : 4;
+        // narrowest blocks that still fit one per CU (TP shards of gate_up: 344 / 172 / 86 tiles -> 64-column blocks)
+        TN = 2;
+        while (TN < 4 && cdiv64(tiles, TN) > 256) ++TN;
         WK = 4;
     } else {
         TN = tiles >= 256 ? 4 : 2;
