@@ -29,7 +29,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, quantize, inter, ret):
+def _worker(rank, world, port, quantize, inter, ret, cfg_kw=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       TGIS_DIST_BACKEND="gloo", TGIS_ALLOW_SHARED_GPU="1")
     import sys
@@ -44,7 +44,7 @@ def _worker(rank, world, port, quantize, inter, ret):
     from tgis_amd.models.flash_causal_lm import FlashCausalLM
     from tgis_amd.pb import generate_pb2 as pb2
 
-    cfg = TinyLlamaConfig(intermediate_size=inter)
+    cfg = TinyLlamaConfig(intermediate_size=inter, **(cfg_kw or {}))
     tensors = tiny_llama_tensors(cfg, seed=21, quantize=quantize, groupsize=64)
     tok = FixtureTokenizer(cfg.vocab_size)
     eng = InferenceEngine(tensors, LlamaConfig(**cfg.to_dict()), torch.float16, quantize, tokenizer=tok, gptq_groupsize=64)
@@ -99,3 +99,23 @@ def test_tp2_product_path_matches_oracle(gpu_device, quantize, inter):
             top2 = torch.topk(want[i]["logits"], 2, dim=-1).values
             flipped = [j for j, (a, b) in enumerate(zip(want[i]["token_ids"].tolist(), ids0[i])) if a != b]
             assert all(float(top2[j, 0] - top2[j, 1]) < 0.75 for j in flipped), f"step {i}: ids {ids0[i]}"
+
+
+def test_tp8_shapes_match_oracle(gpu_device):
+    """Eight ranks on one device: one q/kv head per rank, down_proj shards of 352 rows = 5.5 groups of 64 (regrouped to
+    32, the situation of llama-7B at tp=8), vocab and embedding split eight ways."""
+    kw = dict(hidden_size=512, num_attention_heads=8, num_key_value_heads=8)
+    inter = 2816
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(8, _free_port(), "gptq", inter, ret, kw), nprocs=8, join=True)
+    ids0, logits0 = ret[0]
+    for r in range(1, 8):
+        assert ret[r][0] == ids0
+        assert all(np.array_equal(a, b) for a, b in zip(ret[r][1], logits0))
+    cfg = TinyLlamaConfig(intermediate_size=inter, **kw)
+    ref = LlamaRef(cfg, tiny_llama_tensors(cfg, seed=21, quantize="gptq", groupsize=64), quantize="gptq", groupsize=64)
+    want = ref.generate_greedy(PROMPTS, STEPS, forced=ids0)
+    for i in range(STEPS):
+        err = np.abs(logits0[i] - want[i]["logits"].numpy()).max()
+        assert err < 0.5, f"step {i}: max |logit - oracle| = {err:.3f}"
