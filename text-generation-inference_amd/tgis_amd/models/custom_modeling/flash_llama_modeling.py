@@ -85,18 +85,30 @@ class LlamaRMSNorm:
     __call__ = forward
 
 
+def rope_settings(config):
+    """(theta, linear scaling factor) from either config generation: `rope_theta` + `rope_scaling{type, factor}` (the
+    reference's transformers 4.40, flash_llama_modeling.py:181-191) or `rope_parameters{rope_theta, rope_type, factor}`
+    (transformers >= 5, which dropped the flat attributes)."""
+    params = getattr(config, "rope_parameters", None) or {}
+    theta = getattr(config, "rope_theta", None)
+    if theta is None:
+        theta = params.get("rope_theta", 10000.0)
+    rs = getattr(config, "rope_scaling", None) or {}
+    kind = rs.get("type") or rs.get("rope_type") or params.get("rope_type") or "default"
+    if kind in ("default", None):
+        return float(theta), 1.0
+    if kind == "linear":
+        return float(theta), float(rs.get("factor", params.get("factor", 1.0)))
+    raise ValueError(f"rope_scaling of type {kind} is not supported")
+
+
 class FlashLlamaAttention:
     def __init__(self, prefix: str, config, weights):
         self.num_heads = config.num_attention_heads
         self.hidden_size = config.hidden_size
         self.head_size = self.hidden_size // self.num_heads
-        scaling = 1.0
-        if config.rope_scaling and "type" in config.rope_scaling:
-            if config.rope_scaling["type"] == "linear":
-                scaling = config.rope_scaling.get("factor", 1.0)
-            else:
-                raise ValueError(f"rope_scaling of type {config.rope_scaling['type']} is not supported")
-        self.rotary_emb = PositionRotaryEmbedding.static(dim=self.head_size, base=config.rope_theta,
+        theta, scaling = rope_settings(config)
+        self.rotary_emb = PositionRotaryEmbedding.static(dim=self.head_size, base=theta,
                                                          device=weights.device, scaling_factor=scaling)
         self.softmax_scale = self.head_size ** -0.5
         tp = weights.process_group.size()
