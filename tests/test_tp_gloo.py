@@ -82,7 +82,7 @@ def _worker(rank, world, port, quantize, ret):
 
 @pytest.mark.parametrize("quantize", [None, "gptq"])
 def test_tp2_equals_unsharded_oracle(quantize):
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()  # never fork a process that has run gRPC (or CUDA) threads
     ret = mgr.dict()
     port = _free_port()
     mp.spawn(_worker, args=(2, port, quantize, ret), nprocs=2, join=True)

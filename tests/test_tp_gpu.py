@@ -80,7 +80,7 @@ def _worker(rank, world, port, quantize, inter, ret, cfg_kw=None):
 # (llama-7B at tp=4/8 is in that situation: 11008/4 = 21.5 groups of 128)
 @pytest.mark.parametrize("quantize,inter", [(None, 512), ("gptq", 512), ("gptq", 448)])
 def test_tp2_product_path_matches_oracle(gpu_device, quantize, inter):
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()  # never fork a process that has run gRPC (or CUDA) threads
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), quantize, inter, ret), nprocs=2, join=True)
     ids0, logits0 = ret[0]
@@ -106,7 +106,7 @@ def test_tp8_shapes_match_oracle(gpu_device):
     32, the situation of llama-7B at tp=8), vocab and embedding split eight ways."""
     kw = dict(hidden_size=512, num_attention_heads=8, num_key_value_heads=8)
     inter = 2816
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()  # never fork a process that has run gRPC (or CUDA) threads
     ret = mgr.dict()
     mp.spawn(_worker, args=(8, _free_port(), "gptq", inter, ret, kw), nprocs=8, join=True)
     ids0, logits0 = ret[0]
