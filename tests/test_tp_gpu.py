@@ -119,3 +119,71 @@ def test_tp8_shapes_match_oracle(gpu_device):
     for i in range(STEPS):
         err = np.abs(logits0[i] - want[i]["logits"].numpy()).max()
         assert err < 0.5, f"step {i}: max |logit - oracle| = {err:.3f}"
+
+
+def _bigcode_worker(rank, world, port, dtype_name, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      TGIS_DIST_BACKEND="gloo", TGIS_ALLOW_SHARED_GPU="1")
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "text-generation-inference_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle.tiny_models import TinyBigCodeConfig, tiny_bigcode_tensors
+    from tests.fixture_utils import FixtureTokenizer, prompt_text
+    from tgis_amd.inference_engine.synthetic import InferenceEngine
+    from tgis_amd.models.flash_causal_lm import FlashCausalLM
+    from tgis_amd.pb import generate_pb2 as pb2
+
+    dtype = getattr(torch, dtype_name)
+    cfg = TinyBigCodeConfig()
+    cfg.quantize = None
+    tensors = {k: v.float().to(dtype) for k, v in tiny_bigcode_tensors(cfg, seed=31).items()}
+    tok = FixtureTokenizer(cfg.vocab_size)
+    eng = InferenceEngine(tensors, cfg, dtype, None, tokenizer=tok)
+    lm = FlashCausalLM("tp", None, "synthetic", dtype, None, engine=eng, kv_cache_pages=32)
+    rows = {}
+    orig = lm._process_new_tokens
+
+    def tapped(batch, out, *a, **kw):
+        rows["logits"] = out.detach().float().cpu().numpy().copy()
+        return orig(batch, out, *a, **kw)
+
+    lm._process_new_tokens = tapped
+    reqs = [pb2.Request(id=i, inputs=prompt_text(p), input_length=len(p), truncate=False, max_output_length=STEPS + 2)
+            for i, p in enumerate(PROMPTS)]
+    with lm.context_manager():
+        batch, errs = lm.batch_type.from_pb(pb2.Batch(id=0, requests=reqs), tok, lm.dtype, lm.device, lm.word_embeddings,
+                                            None, lm.use_position_ids)
+        assert not errs
+        ids, logits = [], []
+        for i in range(STEPS):
+            toks, _, errs, _ = lm.generate_token(batch, first=(i == 0))
+            assert not errs
+            ids.append([t.token_id for t in toks])
+            logits.append(rows["logits"])
+    batch.release()
+    ret[rank] = (ids, logits)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tp_santacoder_mqa_matches_oracle(gpu_device, world):
+    """cfg5 family under tensor parallelism: q heads split, the single kv head replicated on every rank (each rank keeps
+    its own copy of the KV pages), vocab-parallel tied embedding/head."""
+    from oracle.santacoder_ref import SantacoderRef
+    from oracle.tiny_models import TinyBigCodeConfig, tiny_bigcode_tensors
+
+    mgr = mp.get_context("spawn").Manager()  # never fork a process that has run gRPC (or CUDA) threads
+    ret = mgr.dict()
+    mp.spawn(_bigcode_worker, args=(world, _free_port(), "float16", ret), nprocs=world, join=True)
+    ids0, logits0 = ret[0]
+    for r in range(1, world):
+        assert ret[r][0] == ids0 and all(np.array_equal(a, b) for a, b in zip(ret[r][1], logits0))
+    cfg = TinyBigCodeConfig()
+    want = SantacoderRef(cfg, tiny_bigcode_tensors(cfg, seed=31)).generate_greedy(PROMPTS, STEPS, forced=ids0)
+    for i in range(STEPS):
+        err = np.abs(logits0[i] - want[i]["logits"].numpy()).max()
+        assert err < 0.1, f"step {i}: max |logit - oracle| = {err:.3f}"
