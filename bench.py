@@ -262,7 +262,7 @@ def main():
                                f"(L_in={L_in}, {W} warm-up + {K} timed steps), greedy",
                    "global_batch": B, "seq_len": int(round(ctx_timed_mean)), "parallelism": f"tp{tp}",
                    "weights": "int4 GPTQ g128" if quantize == "gptq" else dtype_s,
-                   "hip_graph": graphs_used and graphs_kept},
+                   "hip_graph": (lm.graph_mode if tp > 1 else True) if (graphs_used and graphs_kept) else False},
         "step_roofline": {"algorithmic_bytes_per_step": int(ab["total"]), "ms_at_hbm_peak": round(step_roof_ms, 4),
                           "frac_of_hbm_peak": round(step_roof_ms / (elapsed / K * 1e3), 4)},
     }

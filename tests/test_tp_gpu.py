@@ -29,6 +29,13 @@ def _free_port():
     return p
 
 
+def _graph_info(lm):
+    """(mode, captured segments per decode graph) of the model's decode graphs."""
+    if not lm.use_graphs:
+        return ("eager", [])
+    return (lm.graph_mode, [getattr(g.graph, "num_segments", 1) for g in lm._graphs.values() if g.graph is not None])
+
+
 def _worker(rank, world, port, quantize, inter, ret, cfg_kw=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       TGIS_DIST_BACKEND="gloo", TGIS_ALLOW_SHARED_GPU="1")
@@ -72,6 +79,7 @@ def _worker(rank, world, port, quantize, inter, ret, cfg_kw=None):
             logits.append(rows["logits"])
     batch.release()
     ret[rank] = (ids, logits)
+    ret[f"graph{rank}"] = _graph_info(lm)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -165,6 +173,7 @@ def _bigcode_worker(rank, world, port, dtype_name, ret):
             logits.append(rows["logits"])
     batch.release()
     ret[rank] = (ids, logits)
+    ret[f"graph{rank}"] = _graph_info(lm)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -187,3 +196,26 @@ def test_tp_santacoder_mqa_matches_oracle(gpu_device, world):
     for i in range(STEPS):
         err = np.abs(logits0[i] - want[i]["logits"].numpy()).max()
         assert err < 0.1, f"step {i}: max |logit - oracle| = {err:.3f}"
+
+
+def test_tp2_segmented_graphs_equal_eager(gpu_device, monkeypatch):
+    """The default TP decode step is a chain of captured segments with the collectives between them
+    (utils/graph_segments.py): one segment per all-reduce seam, and bit-identical logits to the eager step."""
+    from oracle.tiny_models import TinyLlamaConfig
+
+    got = {}
+    for mode in ("segments", "false"):
+        monkeypatch.setenv("TGIS_TP_GRAPHS", mode)
+        mgr = mp.get_context("spawn").Manager()
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(2, _free_port(), "gptq", 512, ret), nprocs=2, join=True)
+        got[mode] = (ret[0], ret["graph0"], ret["graph1"])
+    (ids_s, logits_s), info_s, info_s1 = got["segments"]
+    (ids_e, logits_e), info_e, _ = got["false"]
+    assert info_e[0] == "eager" and info_s[0] == info_s1[0] == "segments"
+    layers = TinyLlamaConfig().num_hidden_layers
+    # embedding reduce + two reductions per layer + the head's all-gather -> that many seams, one more segment
+    assert info_s[1] and all(n == 2 * layers + 3 for n in info_s[1]), info_s
+    assert ids_s == ids_e
+    for a, b in zip(logits_s, logits_e):
+        assert np.array_equal(a, b)

@@ -12,6 +12,7 @@ import torch
 import torch.distributed
 
 from tgis_amd import native
+from tgis_amd.utils.graph_segments import collective
 from tgis_amd.models.custom_modeling.flash_llama_modeling import KVArgs
 from tgis_amd.utils.layers import (
     TensorParallelColumnLinear,
@@ -195,7 +196,9 @@ class FlashSantacoderModel:
         tok = inputs_embeds if inputs_embeds is not None else self.wte(input_ids)
         hidden_states = tok + pos  # partial sums of both vocab-sharded tables ...
         if self.process_group.size() > 1:  # ... completed by ONE all-reduce (reference :408-414)
-            torch.distributed.all_reduce(hidden_states, group=self.process_group)
+            pg = self.process_group
+            # bound now: a replayed seam must keep reducing THIS tensor, not whatever `hidden_states` names later
+            collective(lambda t=hidden_states: torch.distributed.all_reduce(t, group=pg))
         residual = None
         for layer in self.h:
             hidden_states, residual = layer(hidden_states, residual, position_ids, cu_seqlens_q, kv)

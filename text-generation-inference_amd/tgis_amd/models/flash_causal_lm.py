@@ -29,9 +29,12 @@ from tgis_amd.models.custom_modeling.flash_llama_modeling import KVArgs
 from tgis_amd.models.model import Model
 from tgis_amd.models.types import Batch, GenerateError
 from tgis_amd.pb import generate_pb2
+from tgis_amd.utils.graph_segments import SegmentedGraph
 from tgis_amd.utils.kv_cache import PAGE, PagedKVCache
 from tgis_amd.utils.token_types import InputTokens, TokenInfo
 from tgis_amd.utils.tokens import HeterogeneousNextTokenChooser, get_input_tokens_info, get_token_info
+
+logger = logging.getLogger(__name__)
 
 USE_GRAPHS = os.getenv("TGIS_DISABLE_GRAPHS", "false").lower() not in ("1", "true")
 
@@ -308,9 +311,22 @@ class _DecodeGraph:
             # the capture
             self._step()
             torch.cuda.current_stream().synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.logits, self.ids, self.logprobs = self._step()
+            mode = self.lm.resolve_graph_mode()
+            if mode == "segments":
+                g = SegmentedGraph(self.lm.device)
+                try:
+                    self.logits, self.ids, self.logprobs = g.record(self._step)
+                except Exception as exc:  # keep serving: the eager step needs nothing the capture set up
+                    logger.warning("segmented capture of the decode step failed (%s); running eagerly", exc)
+                    native.clear_error()
+                    self.lm.use_graphs = False
+                    return self._step()
+            else:
+                g = torch.cuda.CUDAGraph()
+                # tp > 1: RCCL's proxy and watchdog threads may call the runtime while this thread captures
+                kw = {"capture_error_mode": "thread_local"} if self.lm.tp_world > 1 else {}
+                with torch.cuda.graph(g, **kw):
+                    self.logits, self.ids, self.logprobs = self._step()
             self.graph = g
         self.graph.replay()
         return self.logits, self.ids, self.logprobs
@@ -354,16 +370,59 @@ class FlashCausalLM(Model):
             kv_cache_pages = self._default_kv_pages()
         self.kv_cache = PagedKVCache(self.num_layers, self.num_kv_heads, self.head_size, kv_cache_pages, dtype,
                                      self.device)
-        # tp > 1: eager launches by default.  The captured step would contain the RCCL all-reduces / all-gather; that
-        # cannot be exercised on a single-GPU box, an aborted capture is not recoverable in-process (measured with
-        # host-mediated collectives: sticky runtime error, then SIGSEGV), and the host keeps up anyway (3.3 ms of
-        # launches per step vs >= 2.9 ms of GPU work per rank once 64 small collectives are in the step).
-        # TGIS_TP_GRAPHS=true opts in.
+        # tp > 1, TGIS_TP_GRAPHS = auto (default) | full | segments | false:
+        #   full      one graph per step with the RCCL all-reduces / all-gather inside it (RCCL is capture-aware);
+        #   segments  a chain of graphs with the collectives launched between them (utils/graph_segments.py);
+        #   false     every kernel launched eagerly (host-bound: 4.4 ms/step whatever the shard size);
+        #   auto      full if a one-collective probe graph captures, replays and reduces correctly on every rank of an
+        #             RCCL group, else segments.
+        # One rank's step at TP=8 shapes, collectives on a world-size-1 RCCL group (tools/tp_segments_rccl1.py):
+        # 2.0 ms full, 3.2 ms segments, 4.4 ms eager.
         tp = engine.world_size if hasattr(engine, "world_size") else 1
         self.tp_world = tp
-        tp_graphs = os.getenv("TGIS_TP_GRAPHS", "false").lower() in ("1", "true")
-        self.use_graphs = USE_GRAPHS and (tp == 1 or tp_graphs)
+        self.process_group = getattr(engine, "process_group", None)
+        tp_mode = os.getenv("TGIS_TP_GRAPHS", "auto").lower()
+        if tp == 1 or tp_mode in ("full", "1", "true"):
+            self.graph_mode = "full"
+        elif tp_mode in ("auto", "segments"):
+            self.graph_mode = tp_mode
+        else:
+            self.graph_mode = None
+        self.use_graphs = USE_GRAPHS and self.graph_mode is not None
         self._graphs = {}
+
+    def resolve_graph_mode(self) -> str:
+        """"full" or "segments"; `auto` is settled once, identically on every rank."""
+        if self.graph_mode == "auto":
+            self.graph_mode = "full" if self._collective_capture_works() else "segments"
+            logger.info("tensor-parallel decode graphs: %s", self.graph_mode)
+        return self.graph_mode
+
+    def _collective_capture_works(self) -> bool:
+        pg = self.process_group
+        if not isinstance(pg, torch.distributed.ProcessGroup) or torch.distributed.get_backend(pg) != "nccl":
+            return False  # host-mediated collectives synchronise: they can never be inside a capture
+        world = pg.size()
+        t = torch.ones(1024, device=self.device, dtype=torch.float32)
+        ok = True
+        try:
+            torch.distributed.all_reduce(t, group=pg)  # communicator up before any capture
+            torch.cuda.synchronize(self.device)
+            t.fill_(1.0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                torch.distributed.all_reduce(t, group=pg)
+            g.replay()
+            g.replay()
+            torch.cuda.synchronize(self.device)
+            ok = bool((t == float(world * world)).all().item())
+        except Exception as exc:
+            logger.warning("RCCL inside a captured graph is not usable here (%s)", exc)
+            native.clear_error()
+            ok = False
+        flag = torch.tensor([1 if ok else 0], device=self.device, dtype=torch.int32)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=pg)
+        return bool(flag.item())
 
     def _default_kv_pages(self) -> int:
         free, _total = torch.cuda.mem_get_info(self.device)

@@ -1,0 +1,91 @@
+"""A decode step captured as a chain of HIP graphs with the collectives launched between them.
+
+For tensor parallelism the step is `segment, all-reduce, segment, all-reduce, ...` (two reductions per layer, one for a
+sharded embedding, one all-gather for the head).  Capturing RCCL inside one big graph is possible but leaves the
+communicator's kernels, its proxy thread and the capture rules entangled; a collective launched between two graph
+replays is exactly the eager call the uncaptured step makes, and the host cost that matters — ~290 kernel launches per
+step — collapses to one graph launch per segment.  The collectives work in place on buffers that belong to the graphs'
+shared memory pool, so addresses stay fixed across replays.
+
+`collective(fn)` is the only hook the layers need: eager mode runs `fn` at once; while a `SegmentedGraph` records it
+closes the open segment, runs `fn` on the recording stream (so that communicators, workspaces and the allocator see
+the same sequence as a replay) and opens the next segment."""
+from typing import Callable, List, Optional, Union
+
+import torch
+
+_recording: Optional["SegmentedGraph"] = None
+
+
+def collective(fn: Callable[[], None]) -> None:
+    if _recording is None:
+        fn()
+    else:
+        _recording._seam(fn)
+
+
+class SegmentedGraph:
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.pool = torch.cuda.graph_pool_handle()
+        self.stream = torch.cuda.Stream(device)
+        self.items: List[Union[torch.cuda.CUDAGraph, Callable[[], None]]] = []
+        self._open: Optional[torch.cuda.CUDAGraph] = None
+
+    # ---- recording ----------------------------------------------------------------------------------------------
+    def _begin(self) -> None:
+        g = torch.cuda.CUDAGraph()
+        # thread_local: RCCL's proxy/watchdog threads may call the runtime while a segment is being captured
+        g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+        self._open = g
+
+    def _end(self) -> None:
+        g, self._open = self._open, None
+        g.capture_end()
+        self.items.append(g)
+
+    def _seam(self, fn: Callable[[], None]) -> None:
+        self._end()
+        fn()
+        self.items.append(fn)
+        self._begin()
+
+    def record(self, body: Callable[[], object]):
+        """Run `body` once on the recording stream, splitting it at every `collective`; returns what `body` returned
+        (tensors of the graphs' pool: valid after each `replay`)."""
+        global _recording
+        if _recording is not None:
+            raise RuntimeError("nested SegmentedGraph.record")
+        torch.cuda.synchronize(self.device)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            _recording = self
+            try:
+                self._begin()
+                out = body()
+                self._end()
+            except BaseException:
+                if self._open is not None:
+                    try:
+                        self._open.capture_end()
+                    except Exception:  # the capture was already invalidated
+                        pass
+                    self._open = None
+                self.items.clear()
+                raise
+            finally:
+                _recording = None
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return out
+
+    # ---- replay -------------------------------------------------------------------------------------------------
+    def replay(self) -> None:
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+            else:
+                it()
+
+    @property
+    def num_segments(self) -> int:
+        return sum(isinstance(it, torch.cuda.CUDAGraph) for it in self.items)

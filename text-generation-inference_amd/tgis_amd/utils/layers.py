@@ -14,6 +14,7 @@ import torch.distributed
 from torch.nn import functional as F
 
 from tgis_amd import native
+from tgis_amd.utils.graph_segments import collective
 
 import os
 
@@ -177,7 +178,8 @@ class TensorParallelHead(SuperLayer):
         gather_in = local.t().contiguous()
         world_out = torch.empty((gather_in.shape[0] * world, gather_in.shape[1]), dtype=local.dtype,
                                 device=local.device)
-        torch.distributed.all_gather_into_tensor(world_out, gather_in, group=self.process_group)
+        pg = self.process_group
+        collective(lambda o=world_out, i=gather_in: torch.distributed.all_gather_into_tensor(o, i, group=pg))
         return world_out.t().contiguous()
 
     __call__ = forward
@@ -217,7 +219,8 @@ class TensorParallelRowLinear(SuperLayer):
         if self.process_group.size() > 1:
             kw.pop("partial", None)  # the all-reduce needs the reduced f16 tensor
             out = self.linear.forward(x, **kw)
-            torch.distributed.all_reduce(out, group=self.process_group)
+            pg = self.process_group
+            collective(lambda t=out: torch.distributed.all_reduce(t, group=pg))
             return out
         return self.linear.forward(x, **kw)
 
@@ -241,7 +244,8 @@ class TensorParallelEmbedding:
         out = native.embedding(input_ids, self.weight, positions=positions, pos_table=pos_table,
                                id_offset=self.min_id)
         if self.reduce and self.process_group.size() > 1:
-            torch.distributed.all_reduce(out, group=self.process_group)
+            pg = self.process_group
+            collective(lambda t=out: torch.distributed.all_reduce(t, group=pg))
         return out
 
     __call__ = forward
