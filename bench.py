@@ -216,6 +216,8 @@ def main():
             elapsed = float(t.item())
         ctx_timed_mean = L_in + 1 + W + (K - 1) / 2.0  # keys attended per step, averaged over the timed steps
         graphs_kept = bool(lm.use_graphs)
+        last = next(iter(lm._graphs.values()), None)
+        logits_finite = bool(torch.isfinite(last.logits).all()) if last is not None and last.logits is not None else None
 
         roofline = None
         if not args.no_roofline:  # every rank runs it (the forward contains collectives when tp > 1)
@@ -262,6 +264,7 @@ def main():
                                f"(L_in={L_in}, {W} warm-up + {K} timed steps), greedy",
                    "global_batch": B, "seq_len": int(round(ctx_timed_mean)), "parallelism": f"tp{tp}",
                    "weights": "int4 GPTQ g128" if quantize == "gptq" else dtype_s,
+                   "logits_finite": logits_finite,
                    "hip_graph": (lm.graph_mode if tp > 1 else True) if (graphs_used and graphs_kept) else False},
         "step_roofline": {"algorithmic_bytes_per_step": int(ab["total"]), "ms_at_hbm_peak": round(step_roof_ms, 4),
                           "frac_of_hbm_peak": round(step_roof_ms / (elapsed / K * 1e3), 4)},

@@ -212,6 +212,29 @@ int tgis_decode_slots(const int32_t* positions, const int32_t* block_tables, int
 int tgis_argmax_logprob(const void* logits, int64_t ld, int64_t B, int64_t V, int logits_f32, int dtype,
                         int64_t* ids_out, float* logprob_out, void* stream);
 
+/* ---- next-token chooser for a heterogeneous batch -------------------------------------------------
+ * One launch for what HeterogeneousNextTokenChooser.__call__ (utils/tokens.py:242-270) does with the
+ * Heterogeneous* processors (utils/logits_process.py:93-402) and Sampling / HeterogeneousSampling
+ * (utils/tokens.py:32-41,336-385), in the reference's order: EOS mask or length penalty, repetition
+ * penalty, temperature, top-k, top-p, typical-p, then argmax (greedy rows) or a categorical draw.
+ *   logits  [B,V] f32 (read only);  scores [B,V] f32 out: the warped scores, -inf where filtered — the
+ *           tensor get_token_info (utils/tokens.py:388-425) takes top-n tokens and ranks from.
+ *   Per-row parameter arrays, each may be NULL (= processor not instantiated): temperature; top_k
+ *   (0 = off); top_p_cut = 1 - top_p as the host rounded it (<= 0 = off); typical_p (>= 1 = off);
+ *   rep_penalty (1 = off) with input_ids [B,L] int64 (row stride ld_ids; padding included, as the
+ *   reference passes it) and exclude_id (the id the penalty leaves alone, -1 = none);
+ *   eos_adjust [B,2] = (mode, factor): mode 1 sets scores[eos_id] = -inf (min_new_tokens), mode 2
+ *   scores[eos_id] += |scores[eos_id]| * factor (length penalty); do_sample [B] (NULL = all greedy).
+ *   rng [B,2] uint64 (seed, offset): the request's Philox4x32-10 stream; offset += 1 per draw.
+ * Outputs: next_ids int64 [B]; next_logprob f32 [B] = log_softmax(scores)[id]; lse f32 [B] =
+ * logsumexp(scores) (log_softmax of a row = scores - lse). */
+int tgis_warp_sample(const float* logits, int64_t ld_logits, float* scores, int64_t ld_scores, int64_t B,
+                     int64_t V, const float* temperature, const int* top_k, const float* top_p_cut,
+                     const float* typical_p, const float* rep_penalty, const int64_t* input_ids,
+                     int64_t ld_ids, int64_t L, int64_t exclude_id, const float* eos_adjust, int64_t eos_id,
+                     const int* do_sample, uint64_t* rng, int64_t* next_ids, float* next_logprob, float* lse,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

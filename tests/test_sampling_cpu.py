@@ -143,3 +143,95 @@ def test_token_info_top_n_rank_and_input_tokens():
     assert math.isnan(it.tokens[0].logprob) and it.tokens[0].rank == 0 and it.tokens[0].top_tokens is None
     assert it.tokens[1].rank == 1 and it.tokens[2].rank == 1
     assert it.tokens[1].logprob == pytest.approx(float(torch.log_softmax(logits[0], -1)[1]))
+
+
+# ---- the oracle of the fused GPU chooser (oracle/sampler_ref.py) --------------------------------------------------
+def test_philox_known_answers():
+    """Random123's published known-answer vectors for philox4x32-10 (kat_vectors: zero, all-ones, pi digits)."""
+    import numpy as np
+
+    from oracle.sampler_ref import philox4x32_10
+
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(int(x) for x in philox4x32_10(np.array(ctr, dtype=np.uint32), key)) == want
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_oracle_warp_row_equals_hf_processors(seed):
+    """oracle.sampler_ref.warp_row, the checker of tgis_warp_sample, against the HF per-row processors in the
+    reference's order (repetition penalty, temperature, top-k, top-p, typical-p)."""
+    from oracle.sampler_ref import warp_row
+
+    V = 500
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(1, V, generator=g) * 4
+    ids = torch.randint(0, V, (1, 30), generator=g)
+    cases = [dict(temperature=0.7), dict(top_k=12), dict(top_p=0.85), dict(typical_p=0.6), dict(rep_penalty=1.3),
+             dict(temperature=1.4, top_k=40, top_p=0.9, typical_p=0.8, rep_penalty=1.15)]
+    for c in cases:
+        want = logits.clone()
+        if "rep_penalty" in c:
+            want = RepetitionPenaltyLogitsProcessor(penalty=c["rep_penalty"])(ids, want)
+        if "temperature" in c:
+            want = TemperatureLogitsWarper(c["temperature"])(ids, want)
+        if "top_k" in c:
+            want = TopKLogitsWarper(c["top_k"])(ids, want)
+        if "top_p" in c:
+            want = TopPLogitsWarper(c["top_p"])(ids, want)
+        if "typical_p" in c:
+            want = TypicalLogitsWarper(mass=c["typical_p"])(ids, want)
+        got = warp_row(logits[0].numpy(), temperature=c.get("temperature", 1.0), top_k=c.get("top_k", 0),
+                       top_p_cut=float(1 - torch.tensor(c["top_p"])) if "top_p" in c else 0.0,
+                       typical_p=c.get("typical_p", 1.0), rep_penalty=c.get("rep_penalty", 1.0),
+                       input_ids=ids[0].tolist())
+        got = torch.from_numpy(got)
+        assert torch.equal(torch.isinf(got), torch.isinf(want[0])), c
+        keep = ~torch.isinf(got)
+        assert torch.allclose(got[keep], want[0][keep], rtol=1e-6, atol=1e-6), c
+
+
+def test_race_choice_is_a_categorical_draw():
+    """The exponential race over Philox uniforms samples softmax(scores): chi-square over 20000 draws."""
+    import numpy as np
+
+    from oracle.sampler_ref import race_choice
+
+    scores = np.array([2.0, 1.0, 0.0, -1.0, -np.inf, 0.5], dtype=np.float32)
+    p = np.exp(scores - scores.max())
+    p /= p.sum()
+    n = 20000
+    counts = np.bincount([race_choice(scores, seed=77, offset=o)[0] for o in range(n)], minlength=6)
+    assert counts[4] == 0
+    live = p > 0
+    chi2 = (((counts - n * p) ** 2)[live] / (n * p[live])).sum()
+    assert chi2 < 20.5  # 4 degrees of freedom: P(chi2 > 20.5) < 4e-4
+
+
+def test_sampling_state_and_seedless_seeds():
+    from tgis_amd.utils import tokens
+
+    s = tokens.Sampling(seed=(1 << 63) + 5)
+    assert s.state == ((1 << 63) + 5 - (1 << 64), 0)
+    s(torch.randn(10))
+    assert s.state[1] == 1
+    # seedless requests: a deterministic function of (base, arrival number), identical on every TP rank
+    tokens.set_seed_base(1234)
+    a = [tokens.Sampling().seed for _ in range(3)]
+    tokens.set_seed_base(1234)
+    b = [tokens.Sampling().seed for _ in range(3)]
+    assert a == b and len(set(a)) == 3
+
+
+def test_eos_adjustments_follow_the_reference_bookkeeping():
+    ps = [_params(min_new_tokens=2), _params(), _params()]
+    ps[1].length_penalty.start_index = 1
+    ps[1].length_penalty.decay_factor = 1.5
+    ch = HeterogeneousNextTokenChooser.from_pb(ps, 2, 0, [False] * 3, torch.float32, "cpu")
+    assert ch._eos_adjustments() == {0: (1.0, 0.0)} and ch.current_tokens == [1, 1, 0]
+    assert ch._eos_adjustments() == {0: (1.0, 0.0)} and ch.current_tokens == [2, 2, 0]
+    assert ch._eos_adjustments() == {1: (2.0, 0.5)} and ch.current_tokens == [2, 3, 0]
+    assert ch._eos_adjustments() == {1: (2.0, 1.25)}

@@ -1,6 +1,6 @@
 """Engine for seeded synthetic checkpoints held in memory (benchmarks, smoke and parity tests): same model
 classes, same `Weights` interface and TP slicing as tgis_native, no files and no tokenizer download.
-The weight recipe is the one SURVEY.md §8(d) defines (N(0, 0.02) dense; GPTQ: random nibbles and zeros,
+The weight recipe is the one SURVEY.md §8(d) defines (N(0, 0.02) dense; GPTQ: random nibbles, random zero nibbles in 0..13,
 scales U(0.5,1.5)*2/15*0.02, g_idx = k // group) — there is no network for real checkpoints."""
 import os
 from typing import Any, Dict, Optional
@@ -47,8 +47,11 @@ def llama_tensors(config, quantize: Optional[str], seed: int, groupsize: int = 1
         G = k // groupsize
         t[f"{name}.qweight"] = torch.randint(-2**31, 2**31 - 1, (k // 8, n), generator=g, device=device,
                                              dtype=torch.int32)
-        t[f"{name}.qzeros"] = torch.randint(-2**31, 2**31 - 1, (G, n // 8), generator=g, device=device,
-                                            dtype=torch.int32)
+        # stored zero nibbles 0..13 (true zero points 1..14, mean 7.5 = the mean nibble): with 0..15 the dequantised
+        # weights carry a common -1 * scale offset, a rank-one term that overflows fp16 activations within a few layers
+        zn = torch.randint(0, 14, (G, n // 8, 8), generator=g, device=device, dtype=torch.int64)
+        zw = (zn << (4 * torch.arange(8, device=device, dtype=torch.int64))).sum(-1)
+        t[f"{name}.qzeros"] = torch.where(zw >= 2**31, zw - 2**32, zw).to(torch.int32)
         t[f"{name}.scales"] = ((torch.rand(G, n, generator=g, device=device) + 0.5) * (2.0 / 15.0) * 0.02
                                ).to(torch.float16)
         t[f"{name}.g_idx"] = (torch.arange(k, device=device, dtype=torch.int32) // groupsize)

@@ -389,6 +389,15 @@ class FlashCausalLM(Model):
         else:
             self.graph_mode = None
         self.use_graphs = USE_GRAPHS and self.graph_mode is not None
+        if tp > 1 and isinstance(self.process_group, torch.distributed.ProcessGroup):
+            # requests without a seed must still draw the same tokens on every rank
+            from tgis_amd.utils import tokens
+
+            base = tokens.seed_base()
+            t = torch.tensor([base >> 32, base & 0xFFFFFFFF], dtype=torch.int64, device=self.device)
+            torch.distributed.broadcast(t, src=0, group=self.process_group)
+            hi, lo = t.tolist()
+            tokens.set_seed_base((hi << 32) | lo)
         self._graphs = {}
 
     def resolve_graph_mode(self) -> str:
@@ -514,31 +523,27 @@ class FlashCausalLM(Model):
             if not prefill:
                 next_token_ids = next_token_ids.clone()  # graph output buffer is reused next step
         else:
-            next_token_ids, next_token_scores, next_token_logprobs = ntc(
-                input_ids=batch.all_input_ids_tensor[:, :batch.max_seqlen], scores=logits)
+            # EOS mask / length penalty, repetition penalty, warpers, argmax or draw, log-softmax at the chosen id:
+            # one launch (tgis_warp_sample) and, below, one device->host copy for the whole batch
+            next_token_ids, next_logprobs, lse, next_token_scores = ntc.choose_fused(
+                batch.all_input_ids_tensor[:, :batch.max_seqlen], logits)
 
         batch.all_input_ids_tensor.scatter_(dim=1, index=batch.position_ids[:, None], src=next_token_ids[:, None])
 
-        if simple:
-            ids_host = next_token_ids.tolist()
-            lps_host = next_logprobs.tolist() if any(ntc.return_logprobs) else None
-            for i, request in enumerate(batch.requests):
-                info = TokenInfo(request_id=request.id, token_id=ids_host[i])
-                if lps_host is not None and request.details.logprobs:
-                    info.logprob = lps_host[i]
-                generated_tokens.append(info)
-                if prefill and request.details.input_toks:
-                    self._append_input_tokens(batch, out, i, request, input_token_infos)
-                batch.input_lengths[i] += 1
-            return next_token_ids
-
-        for i, (request, next_token, scores, logprobs) in enumerate(
-                zip(batch.requests, next_token_ids, next_token_scores, next_token_logprobs)):
+        ids_host = next_token_ids.tolist()
+        lps_host = next_logprobs.tolist() if any(ntc.return_logprobs) else None
+        for i, request in enumerate(batch.requests):
             try:
-                tok_view = next_token.view(-1)
-                scores_view = scores.view(-1, scores.shape[-1])
-                logprobs_view = logprobs.view(-1, logprobs.shape[-1]) if request.details.logprobs else None
-                generated_tokens.append(get_token_info(request, scores_view, tok_view, logprobs_view))
+                if not simple and (request.details.top_n_toks or request.details.ranks):
+                    # top-n tokens and ranks are read from the warped scores of this row (tokens.py:388-425)
+                    row = next_token_scores[i:i + 1]
+                    info = get_token_info(request, row, next_token_ids[i:i + 1],
+                                          row - lse[i] if request.details.logprobs else None)
+                else:
+                    info = TokenInfo(request_id=request.id, token_id=ids_host[i])
+                    if lps_host is not None and request.details.logprobs:
+                        info.logprob = lps_host[i]
+                generated_tokens.append(info)
                 if prefill and request.details.input_toks:
                     self._append_input_tokens(batch, out, i, request, input_token_infos)
             except Exception as e:

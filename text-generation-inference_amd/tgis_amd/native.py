@@ -71,6 +71,8 @@ SIGNATURES = {
     "tgis_embedding": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _vp]),
     "tgis_decode_slots": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp]),
     "tgis_argmax_logprob": (_c_int, [_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _vp, _vp, _vp]),
+    "tgis_warp_sample": (_c_int, [_vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64,
+                                  _c_i64, _c_i64, _vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -501,3 +503,33 @@ def argmax_logprob(logits, ids_out=None, logprob_out=None):
                                            0 if f32 else dtype_code(logits.dtype), _ptr(ids_out),
                                            _ptr(logprob_out), _stream()), "tgis_argmax_logprob")
     return ids_out, logprob_out
+
+
+def warp_sample(logits, temperature=None, top_k=None, top_p_cut=None, typical_p=None, rep_penalty=None,
+                input_ids=None, exclude_id: int = -1, eos_adjust=None, eos_id: int = -1, do_sample=None, rng=None):
+    """The whole next-token chooser for a batch in one launch (tgis_warp_sample).  Returns (next_ids int64 [B],
+    logprob f32 [B] of the chosen ids under the warped scores, lse f32 [B], warped scores f32 [B,V])."""
+    assert logits.dim() == 2 and logits.dtype == torch.float32 and logits.stride(1) == 1
+    B, V = logits.shape
+    dev = logits.device
+    for t, dt in ((temperature, torch.float32), (top_k, torch.int32), (top_p_cut, torch.float32),
+                  (typical_p, torch.float32), (rep_penalty, torch.float32), (do_sample, torch.int32)):
+        assert t is None or (t.dtype == dt and t.numel() == B and t.is_contiguous() and t.device == dev)
+    assert rng is None or (rng.dtype == torch.int64 and rng.shape == (B, 2) and rng.is_contiguous())
+    assert eos_adjust is None or (eos_adjust.dtype == torch.float32 and eos_adjust.shape == (B, 2)
+                                  and eos_adjust.is_contiguous())
+    L = ld_ids = 0
+    if input_ids is not None:
+        assert input_ids.dtype == torch.int64 and input_ids.dim() == 2 and input_ids.shape[0] == B
+        assert input_ids.stride(1) == 1
+        L, ld_ids = input_ids.shape[1], input_ids.stride(0)
+    scores = torch.empty((B, V), dtype=torch.float32, device=dev)
+    ids = torch.empty(B, dtype=torch.int64, device=dev)
+    lps = torch.empty(B, dtype=torch.float32, device=dev)
+    lse = torch.empty(B, dtype=torch.float32, device=dev)
+    _check(
+        load_library().tgis_warp_sample(
+            _ptr(logits), logits.stride(0), _ptr(scores), V, B, V, _ptr(temperature), _ptr(top_k), _ptr(top_p_cut),
+            _ptr(typical_p), _ptr(rep_penalty), _ptr(input_ids), ld_ids, L, exclude_id, _ptr(eos_adjust), eos_id,
+            _ptr(do_sample), _ptr(rng), _ptr(ids), _ptr(lps), _ptr(lse), _stream()), "tgis_warp_sample")
+    return ids, lps, lse, scores

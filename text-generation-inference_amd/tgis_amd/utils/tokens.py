@@ -5,8 +5,13 @@ Mirrors utils/tokens.py of the reference: `Sampling` / `Greedy` (:32-46), `Heter
 choice, log-softmax only when some request wants logprobs), `HeterogeneousSampling` (:336-385),
 `get_token_info` (:388-425) and `get_input_tokens_info` (:429-506).
 
-Difference: when the whole batch is plain greedy with no processors, `choose_greedy_fused` runs one HIP
-kernel (argmax + logprob) and the caller does a single device->host copy instead of one `.item()` per request."""
+Differences: when the whole batch is plain greedy with no processors, `choose_greedy_fused` runs one HIP
+kernel (argmax + logprob) and the caller does a single device->host copy instead of one `.item()` per request;
+for any other batch whose logits are on the GPU, `choose_fused` runs the whole chain (EOS mask / length penalty,
+repetition penalty, warpers, argmax or draw, log-softmax at the chosen id) as one launch of `tgis_warp_sample`.
+The torch processors below remain the definition of the semantics (pinned to HF's per-row processors on CPU) and
+the path for logits that live on the host."""
+import os
 from itertools import chain, repeat
 from typing import List, Optional, Tuple, Union
 
@@ -25,17 +30,59 @@ from tgis_amd.utils.token_types import InputTokens, TokenInfo, TopToken
 
 NONES = repeat(None)
 
+_MASK64 = 0xFFFFFFFFFFFFFFFF
+_seed_base = int.from_bytes(os.urandom(8), "little")
+_seed_count = 0
+
+
+def set_seed_base(base: int) -> None:
+    """Seeds of requests that bring none are `mix(base, n)` for the n-th such request of this process.  Tensor-parallel
+    ranks call this with rank 0's base so that they draw identical tokens for the same request sequence."""
+    global _seed_base, _seed_count
+    _seed_base, _seed_count = base & _MASK64, 0
+
+
+def seed_base() -> int:
+    return _seed_base
+
+
+def _fresh_seed() -> int:
+    global _seed_count
+    _seed_count += 1
+    z = (_seed_base + 0x9E3779B97F4A7C15 * _seed_count) & _MASK64  # splitmix64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK64
+    return z ^ (z >> 31)
+
 
 class Sampling:
-    """softmax(logits) / Exp(1) noise -> argmax == a multinomial draw without a host sync; one generator per
-    request so concatenate / prune keep every request's RNG stream (tokens.py:32-41)."""
+    """One request's random stream: (seed, number of draws so far).  It belongs to the request, so concatenate /
+    prune keep every request's stream (tokens.py:32-41).  On the GPU the draw is made inside `tgis_warp_sample`
+    (Philox keyed by `seed`, counter = `offset`); on host tensors, softmax(logits) / Exp(1) noise -> argmax with a
+    torch generator seeded the same way — a multinomial draw without a sync either way."""
 
     def __init__(self, seed: Optional[int] = None, device="cpu"):
-        self.generator = None if seed is None else torch.Generator(device).manual_seed(seed)
+        self.seed = int(seed) if seed is not None else _fresh_seed()
+        self.offset = 0
+        self.device = device
+        self._generator = None
+
+    @property
+    def generator(self) -> torch.Generator:
+        if self._generator is None:
+            self._generator = torch.Generator(self.device).manual_seed(self.seed)
+        return self._generator
+
+    @property
+    def state(self) -> Tuple[int, int]:
+        """(seed, offset) as two's-complement int64 values for the device-side [B, 2] state tensor."""
+        seed = self.seed & 0xFFFFFFFFFFFFFFFF
+        return (seed - (1 << 64) if seed >= (1 << 63) else seed), self.offset
 
     def __call__(self, logits: torch.Tensor) -> torch.Tensor:
         probs = torch.nn.functional.softmax(logits, -1)
         q = torch.empty_like(probs).exponential_(1, generator=self.generator)
+        self.offset += 1
         return probs.div_(q).argmax()
 
 
@@ -118,6 +165,7 @@ class HeterogeneousNextTokenChooser:
         self.dtype = dtype
         self.device = device
         self.return_logprobs = return_logprobs
+        self._fused = None  # device-side parameter arrays of choose_fused, rebuilt after filter()
 
     @property
     def samplings(self):
@@ -133,18 +181,17 @@ class HeterogeneousNextTokenChooser:
                 and all(ct >= mn for ct, mn in zip(self.current_tokens, self.min_new_tokens)))
 
     def __call__(self, input_ids: torch.Tensor, scores: torch.Tensor):
-        for idx in range(len(self.current_tokens)):
-            cur, lp = self.current_tokens[idx], self.length_penalty[idx]
-            if cur < self.min_new_tokens[idx]:
+        if scores.is_cuda:
+            next_ids, _, lse, warped = self.choose_fused(input_ids, scores)
+            logprobs = warped - lse[:, None] if any(self.return_logprobs) else NONES
+            return next_ids, warped, logprobs
+        for idx, adj in self._eos_adjustments().items():
+            if adj[0] == 1.0:
                 scores[idx, self.eos_token_id] = -float("inf")
-                self.current_tokens[idx] += 1
-            elif lp is not None:
-                tokens_past = cur - lp[0]
-                if tokens_past > 0:
-                    eos = scores[idx, self.eos_token_id]
-                    # penalise through |logit| so negative logits are handled too
-                    scores[idx, self.eos_token_id] = eos + torch.abs(eos) * (pow(lp[1], tokens_past) - 1)
-                self.current_tokens[idx] += 1
+            else:
+                eos = scores[idx, self.eos_token_id]
+                # penalise through |logit| so negative logits are handled too
+                scores[idx, self.eos_token_id] = eos + torch.abs(eos) * adj[1]
         if self.repetition_processor is not None:
             scores = self.repetition_processor(input_ids, scores)
         for warper in self.warpers:
@@ -152,6 +199,79 @@ class HeterogeneousNextTokenChooser:
         next_ids = self.choice(scores)
         logprobs = torch.log_softmax(scores, -1) if any(self.return_logprobs) else NONES
         return next_ids, scores, logprobs
+
+    def _eos_adjustments(self):
+        """{row: (mode, factor)} for this step — mode 1: EOS masked while the request is below min_new_tokens,
+        mode 2: EOS score += |score| * factor (length penalty) — and the step bookkeeping of tokens.py:242-256."""
+        rows = {}
+        for idx in range(len(self.current_tokens)):
+            cur, lp = self.current_tokens[idx], self.length_penalty[idx]
+            if cur < self.min_new_tokens[idx]:
+                rows[idx] = (1.0, 0.0)
+                self.current_tokens[idx] += 1
+            elif lp is not None:
+                tokens_past = cur - lp[0]
+                if tokens_past > 0:
+                    rows[idx] = (2.0, pow(lp[1], tokens_past) - 1)
+                self.current_tokens[idx] += 1
+        return rows
+
+    def _fused_params(self, device):
+        if self._fused is not None:
+            return self._fused
+        B = len(self.do_sample)
+
+        def row_f32(t):
+            return t.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+
+        p = {"temperature": None, "top_k": None, "top_p_cut": None, "typical_p": None, "rep_penalty": None,
+             "exclude_id": -1, "do_sample": None, "rng": None}
+        for w in self.warpers:  # exactly the processors the torch chain would run, with the values it would use
+            if isinstance(w, HeterogeneousTemperatureLogitsWarper):
+                p["temperature"] = row_f32(w.tensor)
+            elif isinstance(w, HeterogeneousTopKLogitsWarper):
+                keep = w.min_tokens_to_keep
+                p["top_k"] = torch.tensor([max(k, keep) if k else 0 for k in w.top_k], dtype=torch.int32,
+                                          device=device)
+            elif isinstance(w, HeterogeneousTopPLogitsWarper):
+                p["top_p_cut"] = row_f32(w.tensor)  # already 1 - top_p
+            elif isinstance(w, HeterogeneousTypicalLogitsWarper):
+                p["typical_p"] = row_f32(w.tensor)
+        if self.repetition_processor is not None:
+            p["rep_penalty"] = row_f32(self.repetition_processor.tensor)
+            ex = self.repetition_processor.id_to_exclude
+            p["exclude_id"] = ex if ex is not None and B != 1 else -1
+        if isinstance(self.choice, HeterogeneousSampling):
+            p["do_sample"] = torch.tensor([int(x) for x in self.do_sample], dtype=torch.int32, device=device)
+            p["rng"] = torch.tensor([s.state if s is not None else (0, 0) for s in self.choice.samplings],
+                                    dtype=torch.int64, device=device)
+        self._fused = p
+        return p
+
+    def choose_fused(self, input_ids: torch.Tensor, scores: torch.Tensor):
+        """(ids int64 [B], logprob f32 [B] of the chosen id under the warped scores, lse f32 [B], warped scores
+        f32 [B, V]) by one launch of tgis_warp_sample; log_softmax(warped)[b] = warped[b] - lse[b]."""
+        p = self._fused_params(scores.device)
+        adj = self._eos_adjustments()
+        eos_adjust = None
+        if adj:
+            host = torch.zeros((len(self.do_sample), 2), dtype=torch.float32)
+            for idx, a in adj.items():
+                host[idx, 0], host[idx, 1] = a
+            eos_adjust = host.to(scores.device, non_blocking=True)
+        logits = scores if scores.dtype == torch.float32 else scores.float()
+        if logits.stride(-1) != 1:
+            logits = logits.contiguous()
+        out = native.warp_sample(
+            logits, temperature=p["temperature"], top_k=p["top_k"], top_p_cut=p["top_p_cut"],
+            typical_p=p["typical_p"], rep_penalty=p["rep_penalty"],
+            input_ids=input_ids if p["rep_penalty"] is not None else None, exclude_id=p["exclude_id"],
+            eos_adjust=eos_adjust, eos_id=self.eos_token_id if eos_adjust is not None else -1,
+            do_sample=p["do_sample"], rng=p["rng"])
+        if p["rng"] is not None:  # host mirror of the offsets the kernel advanced
+            for s in self.choice.sampling_mapping.values():
+                s.offset += 1
+        return out
 
     def choose_greedy_fused(self, scores: torch.Tensor):
         """(ids int64 [B], logprob f32 [B]) by one kernel; valid only when `is_plain_greedy`."""
@@ -188,6 +308,7 @@ class HeterogeneousNextTokenChooser:
             self.choice.filter(indices)
         else:
             self.choice = Greedy()
+        self._fused = None
         return self
 
 
