@@ -34,6 +34,10 @@ CONFIGS = {
                        1024),
     "tinyllama-1.1b": (dict(vocab_size=32000, hidden_size=2048, intermediate_size=5632, num_hidden_layers=22,
                             num_attention_heads=32, num_key_value_heads=4, rms_norm_eps=1e-5), None, "bfloat16", 16, 512),
+    # cfg4 of BASELINE.json (quoted at TP=8; the int4 model + its KV also fit one 288 GB MI355X)
+    "llama2-70b-gptq": (dict(vocab_size=32000, hidden_size=8192, intermediate_size=28672, num_hidden_layers=80,
+                             num_attention_heads=64, num_key_value_heads=8, rms_norm_eps=1e-5), "gptq", "float16", 64,
+                        2048),
     "llama-tiny-gptq": (dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
                              num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5), "gptq", "float16", 4, 64),
 }
