@@ -155,6 +155,7 @@ def main():
 
     rank = int(os.getenv("RANK", "0"))
     world = int(os.getenv("WORLD_SIZE", "1"))
+    os.environ.setdefault("TGIS_DIST_TIMEOUT_S", "600")  # cold boxes: first imports and weight set-up skew the ranks
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")

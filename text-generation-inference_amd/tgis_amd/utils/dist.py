@@ -57,6 +57,8 @@ def initialize_torch_distributed(world_size: int, rank: int):
     if world_size == 1 or os.getenv("DEBUG", None) == "1":
         return FakeGroup(rank, world_size)
     if not torch.distributed.is_initialized():
+        # 60 s as in the reference; benchmarks on a cold box raise it (first imports and weight set-up skew the ranks)
+        timeout = timedelta(seconds=int(os.getenv("TGIS_DIST_TIMEOUT_S", "60")))
         # TGIS_DIST_BACKEND=gloo: host-mediated collectives on GPU tensors, for TP tests on a single-GPU box
         if torch.cuda.is_available() and os.getenv("TGIS_DIST_BACKEND", "nccl") != "gloo":
             from torch.distributed import ProcessGroupNCCL
@@ -64,14 +66,14 @@ def initialize_torch_distributed(world_size: int, rank: int):
             backend = "nccl"  # RCCL on ROCm
             options = ProcessGroupNCCL.Options()
             options.is_high_priority_stream = True
-            options._timeout = timedelta(seconds=60)
+            options._timeout = timeout
         else:
             backend = "gloo"
             options = None
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.distributed.init_process_group(
-            backend=backend, world_size=world_size, rank=rank, timeout=timedelta(seconds=60), pg_options=options)
+            backend=backend, world_size=world_size, rank=rank, timeout=timeout, pg_options=options)
     else:
         print("WARN: torch.distributed is already initialized")
     return torch.distributed.group.WORLD
