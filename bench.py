@@ -260,7 +260,9 @@ def main():
     ab = algorithmic_bytes_per_step(cfg, quantize, B, ctx_timed_mean, tp)
     step_roof_ms = ab["total"] / (HBM_PEAK_GBS * 1e9) * 1e3
     out = {
-        "metric": "decode tokens/sec (Llama-7B int4 GPTQ, batch 32, ctx 1024) + p50 step latency",
+        "metric": ("decode tokens/sec (Llama-7B int4 GPTQ, batch 32, ctx 1024) + p50 step latency"
+                   if (args.config, B, ctx_mean) == ("llama2-7b-gptq", 32, 1024)
+                   else f"decode tokens/sec ({args.config}, batch {B}, ctx {ctx_mean}) + p50 step latency"),
         "value": round(toks_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "p50_step_ms": round(sorted(step_ms)[len(step_ms) // 2], 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16",
