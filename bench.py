@@ -38,6 +38,9 @@ CONFIGS = {
     "llama2-70b-gptq": (dict(vocab_size=32000, hidden_size=8192, intermediate_size=28672, num_hidden_layers=80,
                              num_attention_heads=64, num_key_value_heads=8, rms_norm_eps=1e-5), "gptq", "float16", 64,
                         2048),
+    # cfg5 of BASELINE.json (GPT-BigCode, multi-query attention; quoted at TP=4, fits one GPU)
+    "starcoder-15b": (dict(vocab_size=49152, hidden_size=6144, n_inner=24576, num_hidden_layers=40,
+                           num_attention_heads=48, n_positions=8192), None, "bfloat16", 32, 4096),
     "llama-tiny-gptq": (dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
                              num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5), "gptq", "float16", 4, 64),
 }
@@ -49,7 +52,8 @@ def algorithmic_bytes_per_step(cfg, quantize, B, ctx_mean, tp, groupsize=128):
     E, I, L, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.vocab_size
     H, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
     D = E // H
-    mats = [(E, (H + 2 * Hkv) * D), (E, E), (E, 2 * I), (I, E)]
+    gated = getattr(cfg, "model_type", "llama") == "llama"  # GPT-BigCode: c_fc -> gelu -> c_proj, no gate
+    mats = [(E, (H + 2 * Hkv) * D), (E, E), (E, (2 if gated else 1) * I), (I, E)]
     params = sum(k * n for k, n in mats)
     if quantize == "gptq":
         w = L * (params / 2 + sum((k / groupsize) * n * 2.5 for k, n in mats)) / tp
@@ -162,7 +166,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
 
     from tgis_amd import native
-    from tgis_amd.inference_engine.synthetic import InferenceEngine, llama_tensors
+    from tgis_amd.inference_engine.synthetic import BigCodeConfig, InferenceEngine, bigcode_tensors, llama_tensors
     from tgis_amd.models.custom_modeling.flash_llama_modeling import LlamaConfig
     from tgis_amd.models.flash_causal_lm import FlashCausalLM
     from tgis_amd.testing import SyntheticTokenizer, make_batch_pb
@@ -171,7 +175,8 @@ def main():
     kw, quantize, dtype_s, B, ctx_mean = CONFIGS[args.config]
     B = args.batch or B
     ctx_mean = args.ctx or ctx_mean
-    cfg = LlamaConfig(**kw)
+    bigcode = "n_inner" in kw
+    cfg = BigCodeConfig(**kw) if bigcode else LlamaConfig(**kw)
     dtype = getattr(torch, dtype_s)
     K, W = args.steps, args.warmup
     # context grows by one per step; centre the timed steps on ctx_mean
@@ -180,7 +185,10 @@ def main():
 
     device = torch.device("cuda", rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
-    tensors = llama_tensors(cfg, quantize, seed=1234, device=device, dtype=dtype)
+    if bigcode:
+        tensors = bigcode_tensors(cfg, seed=1234, device=device, dtype=dtype)
+    else:
+        tensors = llama_tensors(cfg, quantize, seed=1234, device=device, dtype=dtype)
     tok = SyntheticTokenizer(cfg.vocab_size)
     eng = InferenceEngine(tensors, cfg, dtype, quantize, tokenizer=tok)
     del tensors
@@ -278,7 +286,7 @@ def main():
     }
     if roofline is not None:
         out["roofline"] = roofline
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and not bigcode:  # the CPU port below is the Llama layer
         out["cpu_baseline"] = cpu_baseline(cfg, quantize, B, int(round(ctx_timed_mean)))
     if rank == 0:
         print(json.dumps(out), flush=True)

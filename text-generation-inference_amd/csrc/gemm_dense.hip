@@ -313,13 +313,50 @@ static DensePlan plan_dense(int64_t K, int64_t N, int64_t M = 32) {
     } else if (tiles >= 512) {
         TN = cdiv64(tiles, 3) <= 256 ? 3 : 4;
         WK = 4;
-    } else {
+    } else if (K * N * 2 < (48ll << 20)) {
+        // small matrices are latency-bound: as many blocks as one round holds, short k-parts (TinyLlama sweeps)
         TN = tiles >= 256 ? 4 : 2;
         const int64_t colblocks = cdiv64(tiles, TN);
         const int64_t want = TN == 4 ? 224 : 256;
         S = std::max<int64_t>(1, std::min<int64_t>(kchunks, (want + colblocks / 2) / colblocks));
-        while (S > 1 && (S - 1) * cdiv64(kchunks, S) >= kchunks) --S;
+        while (S > 1 && (S - 1) * cdiv64(kchunks, S) >= kchunks) --S;  // no empty last split
         WK = TN == 4 ? 2 : (cdiv64(kchunks, S) >= 4 ? 4 : 2);
+    } else {
+        // Narrow / medium N, bandwidth-bound sizes: pick (TN, WK, S) by a two-term model of a launch — a dense block streams
+        // KR x 32 TN x 2 bytes; blocks run in rounds of one per CU (two for the half-size LDS of WK = 2); a round takes
+        // max(block bytes / per-CU rate, round bytes / chip rate) + a fixed ramp; each extra split adds slab traffic.
+        // The rates are the ones measured on MI355X (one block alone ~50 GB/s, the chip 5.9 TB/s for this access
+        // pattern).  It reproduces the measured 72 us of 24576x6144 at (2,4,S=3: 288 blocks = two rounds) and picks
+        // (3,4,S=4: 256 blocks, one round) instead.
+        double best = 1e30;
+        TN = 2, WK = 4, S = 1;
+        for (int tn = 2; tn <= 4; ++tn)
+            for (int wk = 4; wk >= 2; wk -= 2) {
+                if (tn == 3 && wk == 2) continue;  // not instantiated
+                for (int64_t sp = 1; sp <= std::min<int64_t>(16, kchunks); ++sp) {
+                    int64_t krc = cdiv64(cdiv64(kchunks, sp), wk) * wk;
+                    if (sp > 1 && (sp - 1) * krc >= kchunks) continue;  // an empty last split
+                    const int64_t blocks = cdiv64(tiles, tn) * sp;
+                    const double block_bytes = (double)krc * DKC * tn * 32 * 2;
+                    const int64_t slots = wk == 2 ? 512 : 256;
+                    const double cu_rate = wk == 2 ? 25.0 : 50.0;  // GB/s per block: two half-LDS blocks share a CU
+                    double ns = sp > 1 ? 500.0 * sp : 0.0;
+                    for (int64_t left = blocks; left > 0; left -= slots) {
+                        const int64_t n = std::min(left, slots);
+                        ns += std::max(block_bytes / cu_rate, n * block_bytes / 5900.0) + 4000.0;
+                    }
+                    if (ns < best - 1.0) {
+                        best = ns;
+                        TN = tn, WK = wk, S = sp;
+                    }
+                }
+            }
+        if (const char* ov = getenv("TGIS_DENSE_PLAN")) {  // tuning hook: "S,WK,TN"
+            int sp = 0, wk = 0, tn = 0;
+            if (sscanf(ov, "%d,%d,%d", &sp, &wk, &tn) == 3 && sp >= 1 && (wk == 2 || wk == 4) && tn >= 2 && tn <= 4 &&
+                !(tn == 3 && wk == 2))
+                TN = tn, WK = wk, S = sp;
+        }
     }
     int64_t KRc = cdiv64(kchunks, S);
     if (KRc < WK) WK = 2;

@@ -72,3 +72,52 @@ def llama_tensors(config, quantize: Optional[str], seed: int, groupsize: int = 1
     t["model.norm.weight"] = torch.ones(E, device=device, dtype=dtype)
     t["lm_head.weight"] = (torch.randn(V, E, generator=g, device=device) * 0.02 * head_scale).to(dtype)
     return t
+
+
+class BigCodeConfig:
+    """The fields of HF's GPTBigCodeConfig that FlashSantacoderForCausalLM reads (multi-query attention)."""
+    model_type = "gpt_bigcode"
+
+    def __init__(self, vocab_size=49152, hidden_size=6144, n_inner=24576, num_hidden_layers=40, num_attention_heads=48,
+                 layer_norm_epsilon=1e-5, n_positions=8192, activation_function="gelu_pytorch_tanh"):
+        self.vocab_size, self.hidden_size, self.n_inner = vocab_size, hidden_size, n_inner
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.layer_norm_epsilon, self.n_positions = layer_norm_epsilon, n_positions
+        self.activation_function = activation_function
+        self.multi_query = True
+        self.architectures = ["GPTBigCodeForCausalLM"]
+        self.transpose = False
+        self.pad_token_id, self.bos_token_id, self.eos_token_id = 0, 0, 0
+        self.tie_word_embeddings = True
+        # the names the benchmark's byte accounting shares with Llama
+        self.intermediate_size = n_inner
+        self.num_key_value_heads = 1
+
+
+def bigcode_tensors(config, seed: int, device="cpu", dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    """Seeded full GPT-BigCode checkpoint in HF naming (tied head): N(0, 1/sqrt(fan_in)) weights, small biases."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    E, I, V = config.hidden_size, config.n_inner, config.vocab_size
+    D = E // config.num_attention_heads
+    t: Dict[str, torch.Tensor] = {}
+
+    def lin(name, n, k):
+        t[f"{name}.weight"] = (torch.randn(n, k, generator=g, device=device) * k ** -0.5).to(dtype)
+        t[f"{name}.bias"] = (torch.randn(n, generator=g, device=device) * 0.02).to(dtype)
+
+    def ln(name):
+        t[f"{name}.weight"] = torch.ones(E, device=device, dtype=dtype)
+        t[f"{name}.bias"] = torch.zeros(E, device=device, dtype=dtype)
+
+    t["transformer.wte.weight"] = (torch.randn(V, E, generator=g, device=device) * 0.02).to(dtype)
+    t["transformer.wpe.weight"] = (torch.randn(config.n_positions, E, generator=g, device=device) * 0.02).to(dtype)
+    for i in range(config.num_hidden_layers):
+        p = f"transformer.h.{i}"
+        ln(f"{p}.ln_1")
+        lin(f"{p}.attn.c_attn", E + 2 * D, E)
+        lin(f"{p}.attn.c_proj", E, E)
+        ln(f"{p}.ln_2")
+        lin(f"{p}.mlp.c_fc", I, E)
+        lin(f"{p}.mlp.c_proj", E, I)
+    ln("transformer.ln_f")
+    return t
