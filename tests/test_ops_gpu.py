@@ -155,7 +155,8 @@ def _paged_setup(gpu_device, dtype, lens_ctx, lens_q, H, Hkv, D, seed, num_pages
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("H,Hkv,D", [(32, 32, 128), (32, 4, 64), (8, 1, 128), (12, 1, 128), (48, 1, 128), (6, 2, 64)])
+@pytest.mark.parametrize("H,Hkv,D", [(32, 32, 128), (32, 4, 64), (8, 1, 128), (12, 1, 128), (48, 1, 128), (6, 2, 64),
+                                      (20, 1, 128), (80, 1, 64), (64, 2, 128)])  # groups of 2, 5 and 2 16-head chunks
 def test_rope_kv_attention_prefill_then_decode(nat, gpu_device, dtype, H, Hkv, D):
     """Prefill (ragged lengths incl. 1 and non-multiples of 32) then one decode step, against the oracle's
     rotary + varlen attention.  Also checks the cache contents bit-exactly against the rotated k / v."""

@@ -5,6 +5,10 @@
 //
 // One workgroup = 4 waves handles one (sequence, kv head, 16-column q tile, key split).  The 16 MFMA
 // columns are (q token, q head of the GQA group) pairs, so one K/V stream serves the whole group.
+// Groups wider than 16 heads (multi-query attention: 48 q heads on one kv head) take CH 16-head chunks per block:
+// the wave keeps CH sets of Q fragments, softmax statistics and O accumulators and applies every K/V fragment it
+// loads to all of them, so K/V still stream from HBM once (one block per chunk re-read them once per chunk — the
+// chunks land on different XCDs, i.e. different L2s: 47 us per Starcoder-15B launch where the bytes need 11).
 // Per 32-token page and wave:
 //   S^T[tok][col] = K[tok][:] . Q[col][:]      A = K fragment (1 KiB contiguous loads), B = Q^T
 //   online softmax per column: the column's statistics live in lane (l & 15) of every 16-lane row
@@ -20,7 +24,7 @@ namespace {
 
 
 // NW = waves per workgroup (the key range of a block is dealt page-by-page to its waves)
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, int CH>
 __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     using V8 = typename VecT<T>::x8;
     constexpr int KS = D / 32;  // k-steps of the QK^T MFMA
@@ -29,7 +33,7 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int col = lane & 15, c = lane >> 4;
     const int qt = blockIdx.x;
-    const int hk = blockIdx.y / a.HC, hc = blockIdx.y % a.HC;
+    const int hk = blockIdx.y / a.HCB, hc0 = (blockIdx.y % a.HCB) * CH;  // first 16-head chunk of this block
     const int b = blockIdx.z / a.NS, split = blockIdx.z % a.NS;
 
     const int q0 = a.cu_q[b], q_len = a.cu_q[b + 1] - q0;
@@ -37,34 +41,44 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     if (t0 >= q_len) return;
     const int ctx = a.ctx_lens[b];
     const int tq = col / a.Gp, g = col % a.Gp;
-    const int head = hk * a.G + hc * 16 + g;
-    const bool col_valid = (g < a.Gc) && (hc * 16 + g < a.G) && (t0 + tq < q_len);
-    // this column may attend to key positions < kmax
-    const int kmax = col_valid ? (ctx - q_len + t0 + tq + 1) : 0;
+    bool col_valid[CH];
+    int kmax[CH];  // this column may attend to key positions < kmax
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        col_valid[ch] = (g < a.Gc) && ((hc0 + ch) * 16 + g < a.G) && (t0 + tq < q_len);
+        kmax[ch] = col_valid[ch] ? (ctx - q_len + t0 + tq + 1) : 0;
+    }
     const int kend = ctx - q_len + min(q_len, t0 + a.TQ);  // keys needed by any column of the tile
     const int pages = (kend + 31) >> 5;
     const int pps = (pages + a.NS - 1) / a.NS;
     const int pbeg = split * pps, pend = min(pages, pbeg + pps);
 
     // Q^T fragments (B operand): lane supplies Q[col][ks*32 + c*8 .. +8]
-    V8 qf[KS];
-    {
+    V8 qf[CH][KS];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        const int head = hk * a.G + (hc0 + ch) * 16 + g;
         const T* qp = reinterpret_cast<const T*>(a.q) + (int64_t)(q0 + t0 + tq) * a.ld_q + (int64_t)head * D + c * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (col_valid) {
-                qf[ks] = ld16<V8>(qp + ks * 32);
+            if (col_valid[ch]) {
+                qf[ch][ks] = ld16<V8>(qp + ks * 32);
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) qf[ks][e] = (T)0.f;
+                for (int e = 0; e < 8; ++e) qf[ch][ks][e] = (T)0.f;
             }
         }
     }
 
-    f32x4 o[NB];
+    f32x4 o[CH][NB];
+    float m[CH], lsum[CH];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) o[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m = NEG_BIG, lsum = 0.f;
+    for (int ch = 0; ch < CH; ++ch) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) o[ch][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m[ch] = NEG_BIG;
+        lsum[ch] = 0.f;
+    }
 
     const int32_t* btrow = a.bt + (int64_t)b * a.max_pages;
     int p = pbeg + w;
@@ -82,83 +96,93 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) vf[nb] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(vb + nb * 512));
 
-        f32x4 s[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s[t] = mfma16(kf[t][ks], qf[ks], s[t]);
-        }
-        // scale, causal/length mask, tile max
-        float tmax = NEG_BIG;
         const int kp0 = p * 32 + c * 4;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int ch = 0; ch < CH; ++ch) {
+            f32x4 s[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = s[t][r] * a.scale_log2;
-                v = (kp0 + t * 16 + r < kmax) ? v : NEG_BIG;
-                s[t][r] = v;
-                tmax = fmaxf(tmax, v);
+            for (int t = 0; t < 2; ++t) {
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) s[t] = mfma16(kf[t][ks], qf[ch][ks], s[t]);
             }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m, tmax);
-        const float alpha = exp2f(m - m_new);
-        m = m_new;
-        V8 pf;
-        float psum = 0.f;
+            // scale, causal/length mask, tile max
+            float tmax = NEG_BIG;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // masked entries contribute exactly 0 even while m is still NEG_BIG
-                float pv = (s[t][r] > 0.5f * NEG_BIG) ? exp2f(s[t][r] - m_new) : 0.f;
-                T pt = from_f32<T>(pv);
-                pf[t * 4 + r] = pt;
-                psum += to_f32(pt);  // normaliser from the rounded P, as flash-attention does
+                for (int r = 0; r < 4; ++r) {
+                    float v = s[t][r] * a.scale_log2;
+                    v = (kp0 + t * 16 + r < kmax[ch]) ? v : NEG_BIG;
+                    s[t][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m[ch], tmax);
+            const float alpha = exp2f(m[ch] - m_new);
+            m[ch] = m_new;
+            V8 pf;
+            float psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // masked entries contribute exactly 0 even while m is still NEG_BIG
+                    float pv = (s[t][r] > 0.5f * NEG_BIG) ? exp2f(s[t][r] - m_new) : 0.f;
+                    T pt = from_f32<T>(pv);
+                    pf[t * 4 + r] = pt;
+                    psum += to_f32(pt);  // normaliser from the rounded P, as flash-attention does
+                }
+            lsum[ch] = lsum[ch] * alpha + psum;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                o[ch][nb] *= alpha;
+                o[ch][nb] = mfma16(vf[nb], pf, o[ch][nb]);
             }
-        lsum = lsum * alpha + psum;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            o[nb] *= alpha;
-            o[nb] = mfma16(vf[nb], pf, o[nb]);
         }
         pg = pg_next;
     }
 
     // ---- combine the 4 waves through LDS ----------------------------------------------------------
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
-    float* so = reinterpret_cast<float*>(smem);          // [NW][D][16]
-    float* sml = so + NW * D * 16;                       // [NW][2][16]
+    float* so = reinterpret_cast<float*>(smem);          // [CH][NW][D][16]
+    float* sml = so + CH * NW * D * 16;                  // [CH][NW][2][16]
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int ch = 0; ch < CH; ++ch) {
+        float ls = lsum[ch];
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) so[(w * D + nb * 16 + c * 4 + r) * 16 + col] = o[nb][r];
-    if (c == 0) {
-        sml[(w * 2 + 0) * 16 + col] = m;
-        sml[(w * 2 + 1) * 16 + col] = lsum;
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) so[((ch * NW + w) * D + nb * 16 + c * 4 + r) * 16 + col] = o[ch][nb][r];
+        if (c == 0) {
+            sml[((ch * NW + w) * 2 + 0) * 16 + col] = m[ch];
+            sml[((ch * NW + w) * 2 + 1) * 16 + col] = ls;
+        }
     }
     __syncthreads();
-    // thread -> (column j, 8 consecutive d)
-    for (int item = tid; item < 16 * (D / 8); item += 64 * NW) {
-        const int j = item & 15, dc = item >> 4;
+    // thread -> (chunk, column j, 8 consecutive d)
+    for (int item = tid; item < CH * 16 * (D / 8); item += 64 * NW) {
+        const int j = item & 15, dc = (item >> 4) % (D / 8), ch = item / (16 * (D / 8));
+        const int hc = hc0 + ch;
         const int tqj = j / a.Gp, gj = j % a.Gp;
         if (!(gj < a.Gc && hc * 16 + gj < a.G && t0 + tqj < q_len)) continue;
+        const float* soc = so + ch * NW * D * 16;
+        const float* smc = sml + ch * NW * 2 * 16;
         float mw[NW], mstar = NEG_BIG;
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
-            mw[k] = sml[(k * 2) * 16 + j];
+            mw[k] = smc[(k * 2) * 16 + j];
             mstar = fmaxf(mstar, mw[k]);
         }
         float l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
             float f = exp2f(mw[k] - mstar);
-            l += sml[(k * 2 + 1) * 16 + j] * f;
+            l += smc[(k * 2 + 1) * 16 + j] * f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += so[(k * D + dc * 8 + e) * 16 + j] * f;
+            for (int e = 0; e < 8; ++e) acc[e] += soc[(k * D + dc * 8 + e) * 16 + j] * f;
         }
         const int64_t tokidx = q0 + t0 + tqj;
         const int headj = hk * a.G + hc * 16 + gj;
@@ -222,15 +246,35 @@ static AttnGeom geom(int H, int Hkv) {
     return g;
 }
 
+// 16-head chunks one decode block serves (register budget: 3 sets of O accumulators at D = 128)
+static int chunks_per_block(int HC, int64_t max_q_len) { return (max_q_len == 1 && HC > 1) ? std::min(HC, 3) : 1; }
+
+template <typename T, int D, int CH>
+static void launch_attn_nw(const AttnArgs& a, dim3 grid, hipStream_t st, int nw) {
+    const size_t lds = (size_t)CH * (nw * D * 16 + nw * 2 * 16) * sizeof(float);
+    if (nw == 1) {
+        hipLaunchKernelGGL((attn_paged_kernel<T, D, 1, CH>), grid, dim3(64), lds, st, a);
+    } else if (nw == 2) {
+        hipLaunchKernelGGL((attn_paged_kernel<T, D, 2, CH>), grid, dim3(128), lds, st, a);
+    } else {
+        static bool attr = false;  // CH = 3, D = 128: 98 KB of combine scratch
+        if (!attr && lds > 48 * 1024) {
+            (void)hipFuncSetAttribute((const void*)attn_paged_kernel<T, D, 4, CH>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL((attn_paged_kernel<T, D, 4, CH>), grid, dim3(256), lds, st, a);
+    }
+}
+
 template <typename T, int D>
-static int launch_attn(const AttnArgs& a, dim3 grid, int64_t total_q, hipStream_t st, int nw) {
-    const size_t lds = (size_t)(nw * D * 16 + nw * 2 * 16) * sizeof(float);
-    if (nw == 1)
-        hipLaunchKernelGGL((attn_paged_kernel<T, D, 1>), grid, dim3(64), lds, st, a);
-    else if (nw == 2)
-        hipLaunchKernelGGL((attn_paged_kernel<T, D, 2>), grid, dim3(128), lds, st, a);
+static int launch_attn(const AttnArgs& a, dim3 grid, int64_t total_q, hipStream_t st, int nw, int ch) {
+    if (ch == 3)
+        launch_attn_nw<T, D, 3>(a, grid, st, nw);
+    else if (ch == 2)
+        launch_attn_nw<T, D, 2>(a, grid, st, nw);
     else
-        hipLaunchKernelGGL((attn_paged_kernel<T, D, 4>), grid, dim3(256), lds, st, a);
+        launch_attn_nw<T, D, 1>(a, grid, st, nw);
     TGIS_CHECK_LAUNCH();
     if (a.NS > 1) {
         hipLaunchKernelGGL((attn_combine_kernel<T, D>), dim3((unsigned)(total_q * a.H)), dim3(64), 0, st, a.ws_o,
@@ -246,11 +290,14 @@ extern "C" int tgis_attn_num_splits(int64_t B, int Hkv, int H, int64_t max_q_len
     if (B <= 0 || Hkv <= 0 || H <= 0 || H % Hkv != 0 || max_q_len != 1) return 1;  // splits: decode only
     AttnGeom g = geom(H, Hkv);
     int64_t q_tiles = cdiv64(max_q_len, g.TQ);
-    int64_t base = B * Hkv * g.HC * q_tiles;
+    const int ch = chunks_per_block(g.HC, max_q_len);
+    int64_t base = B * Hkv * cdiv64(g.HC, ch) * q_tiles;
     int64_t pages = cdiv64(std::max<int64_t>(max_ctx, 1), 32);
     // ~512 blocks: enough to fill 256 CUs twice; more, thinner blocks lose to the dispatch ramp and the combine pass
     // (tools/split_sweep.py: B=32 MQA ctx 4096: 19 us at 8 splits vs 26 us at 32)
-    int64_t ns = cdiv64(512, base);
+    // (multi-chunk blocks hold three sets of accumulators: one block per CU, so one round of 256 —
+    //  tools/attn_mqa.py, 48 q heads on 1 kv head, B=32 ctx 4096: 26.7 us at 8 splits, 38 at 16, 32 at 4)
+    int64_t ns = cdiv64(ch > 1 ? 256 : 512, base);
     ns = std::min<int64_t>(ns, cdiv64(pages, 4));  // at least one page per wave
     ns = std::max<int64_t>(1, std::min<int64_t>(ns, 64));
     return (int)ns;
@@ -295,6 +342,8 @@ extern "C" int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, 
     a.Gp = g.Gp;
     a.TQ = g.TQ;
     a.HC = g.HC;
+    const int ch = chunks_per_block(g.HC, max_q_len);
+    a.HCB = (g.HC + ch - 1) / ch;
     a.NS = num_splits;
     a.scale_log2 = scale * 1.4426950408889634f;
     a.ws_o = nullptr;
@@ -315,9 +364,9 @@ extern "C" int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, 
         return tgis_launch_attn_prefill(a, B, Hkv, D, max_q_len, dtype, st);
     }
     int64_t q_tiles = cdiv64(max_q_len, g.TQ);
-    TGIS_CHECK_ARG(q_tiles <= 2147483647LL && (int64_t)Hkv * g.HC <= 65535 && B * num_splits <= 65535,
+    TGIS_CHECK_ARG(q_tiles <= 2147483647LL && (int64_t)Hkv * a.HCB <= 65535 && B * num_splits <= 65535,
                    "tgis_attn_paged: grid too large");
-    dim3 grid((unsigned)q_tiles, (unsigned)(Hkv * g.HC), (unsigned)(B * num_splits));
+    dim3 grid((unsigned)q_tiles, (unsigned)(Hkv * a.HCB), (unsigned)(B * num_splits));
     // waves per block: with >= 1024 (sequence, kv head) blocks the chip is full either way and 2-wave blocks halve
     // the page-count imbalance between a block's waves (33 pages over 4 waves = 9/8/8/8; over 2 = 17/16)
     const int64_t nblocks = (int64_t)grid.x * grid.y * grid.z;
@@ -326,10 +375,10 @@ extern "C" int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, 
     if (const char* e = getenv("TGIS_ATTN_NW")) nw = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 4;
     TgisTimedScope timed(TGIS_OP_ATTN, st);
     if (dtype == TGIS_F16) {
-        if (D == 128) return launch_attn<f16, 128>(a, grid, total_q, st, nw);
-        return launch_attn<f16, 64>(a, grid, total_q, st, nw);
+        if (D == 128) return launch_attn<f16, 128>(a, grid, total_q, st, nw, ch);
+        return launch_attn<f16, 64>(a, grid, total_q, st, nw, ch);
     } else {
-        if (D == 128) return launch_attn<bf16, 128>(a, grid, total_q, st, nw);
-        return launch_attn<bf16, 64>(a, grid, total_q, st, nw);
+        if (D == 128) return launch_attn<bf16, 128>(a, grid, total_q, st, nw, ch);
+        return launch_attn<bf16, 64>(a, grid, total_q, st, nw, ch);
     }
 }

@@ -13,6 +13,7 @@ struct AttnArgs {
     const int32_t* cu_q;
     void* out;
     int H, Hkv, G, Gc, Gp, TQ, HC, NS;
+    int HCB;  // decode kernel: blocks per kv head along the 16-head chunks (HC / chunks per block)
     float scale_log2;
     float* ws_o;   // [total_q][H][NS][D]
     float* ws_ml;  // [total_q][H][NS][2]
