@@ -12,7 +12,11 @@ processors.
 `philox4x32_10` is the Random123 generator (Salmon et al., SC'11), pinned to its published known-answer vectors in
 tests/test_sampling_cpu.py; `race_choice` restates the draw: argmax_i p_i / E_i with E_i = -log(u_i) ~ Exp(1), the form
 the reference's `Sampling` (utils/tokens.py:32-41, `torch.multinomial`) samples from — a categorical draw from
-softmax(scores)."""
+softmax(scores).
+
+Pinned: `warp_row` against tests/golden/chooser_reference.npz — outputs of the reference's own
+HeterogeneousNextTokenChooser run on CPU in the build container (tests/golden/make_chooser_fixture.py) — and against
+the HF per-row processors; `philox4x32_10` against Random123's known answers (tests/test_sampling_cpu.py)."""
 from typing import Optional, Sequence, Tuple
 
 import numpy as np

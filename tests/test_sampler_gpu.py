@@ -236,3 +236,32 @@ def test_chooser_gpu_equals_host_chain(nat, gpu_device):
     want2, _, _ = full(all_ids.to(gpu_device), logits2)
     got2, _, _ = carried(all_ids[[2, 4]].to(gpu_device), logits2[[2, 4]])
     assert got2.tolist() == [int(want2[2]), int(want2[4])]
+
+
+def test_fused_chooser_equals_reference_golden(nat, gpu_device):
+    """tests/golden/chooser_reference.npz: outputs of the reference's own HeterogeneousNextTokenChooser (CPU, fp32),
+    generated by tests/golden/make_chooser_fixture.py.  The same requests through the GPU launch, two consecutive
+    calls: filtered sets and greedy ids exact; surviving scores and log-probabilities to fp32 rounding."""
+    import os
+
+    from tgis_amd.pb import generate_pb2 as pb
+    from tgis_amd.utils.tokens import HeterogeneousNextTokenChooser
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chooser_reference.npz"))
+    for name in sorted({k.split(".")[0] for k in z.files}):
+        n = len([k for k in z.files if k.startswith(f"{name}.params.")])
+        params = [pb.NextTokenChooserParameters.FromString(z[f"{name}.params.{i}"].tobytes()) for i in range(n)]
+        ch = HeterogeneousNextTokenChooser.from_pb(params, 2, 2, [True] * n, torch.float32, gpu_device)
+        ids = torch.from_numpy(z[f"{name}.ids"]).to(gpu_device)
+        for step in range(2):
+            next_ids, scores, logprobs = ch(ids, torch.from_numpy(z[f"{name}.{step}.logits"]).to(gpu_device))
+            scores, logprobs, next_ids = scores.cpu(), logprobs.cpu(), next_ids.cpu()
+            want = torch.from_numpy(z[f"{name}.{step}.scores"])
+            assert torch.equal(torch.isinf(scores), torch.isinf(want)), (name, step)
+            keep = ~torch.isinf(want)
+            assert torch.allclose(scores[keep], want[keep], rtol=1e-6, atol=1e-6)
+            assert torch.allclose(logprobs[keep], torch.from_numpy(z[f"{name}.{step}.logprobs"])[keep], rtol=1e-5, atol=1e-5)
+            greedy = torch.from_numpy(z[f"{name}.{step}.greedy_rows"])
+            assert torch.equal(next_ids[greedy], torch.from_numpy(z[f"{name}.{step}.next_ids"])[greedy])
+            for b in range(n):  # sampled rows: drawn from inside the reference's filtered set
+                assert not torch.isinf(want[b, int(next_ids[b])])

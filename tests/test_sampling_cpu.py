@@ -235,3 +235,62 @@ def test_eos_adjustments_follow_the_reference_bookkeeping():
     assert ch._eos_adjustments() == {0: (1.0, 0.0)} and ch.current_tokens == [2, 2, 0]
     assert ch._eos_adjustments() == {1: (2.0, 0.5)} and ch.current_tokens == [2, 3, 0]
     assert ch._eos_adjustments() == {1: (2.0, 1.25)}
+
+
+# ---- golden vectors from the reference's own chooser (tests/golden/make_chooser_fixture.py) -----------------------
+def _chooser_golden():
+    import os
+
+    import numpy as np
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chooser_reference.npz"))
+    cases = sorted({k.split(".")[0] for k in z.files})
+    for name in cases:
+        n = len([k for k in z.files if k.startswith(f"{name}.params.")])
+        params = [pb.NextTokenChooserParameters.FromString(z[f"{name}.params.{i}"].tobytes()) for i in range(n)]
+        yield name, params, z
+
+
+def test_host_chooser_equals_reference_golden():
+    """The torch chain (the semantics the GPU kernel is held to) against the reference's chooser, two consecutive calls:
+    filtered sets and greedy ids exact, surviving scores and log-probabilities to fp32 rounding."""
+    for name, params, z in _chooser_golden():
+        ch = HeterogeneousNextTokenChooser.from_pb(params, 2, 2, [True] * len(params), torch.float32, "cpu")
+        ids = torch.from_numpy(z[f"{name}.ids"])
+        for step in range(2):
+            next_ids, scores, logprobs = ch(ids, torch.from_numpy(z[f"{name}.{step}.logits"]).clone())
+            want = torch.from_numpy(z[f"{name}.{step}.scores"])
+            assert torch.equal(torch.isinf(scores), torch.isinf(want)), (name, step)
+            keep = ~torch.isinf(want)
+            assert torch.allclose(scores[keep], want[keep], rtol=1e-6, atol=1e-6)
+            assert torch.allclose(logprobs[keep], torch.from_numpy(z[f"{name}.{step}.logprobs"])[keep], rtol=1e-5, atol=1e-5)
+            greedy = torch.from_numpy(z[f"{name}.{step}.greedy_rows"])
+            assert torch.equal(next_ids[greedy], torch.from_numpy(z[f"{name}.{step}.next_ids"])[greedy])
+
+
+def test_oracle_warp_row_equals_reference_golden():
+    """oracle/sampler_ref.py (the checker of tgis_warp_sample) against the same vectors, row by row."""
+    import numpy as np
+
+    from oracle.sampler_ref import warp_row
+
+    for name, params, z in _chooser_golden():
+        B = len(params)
+        ch = HeterogeneousNextTokenChooser.from_pb(params, 2, 2, [True] * B, torch.float32, "cpu")  # host bookkeeping only
+        sampled = any(p.temperature != 0 for p in params)
+        ids = z[f"{name}.ids"]
+        for step in range(2):
+            adj = ch._eos_adjustments()
+            for b, p in enumerate(params):
+                mode, factor = adj.get(b, (0.0, 0.0))
+                rep = p.repetition_penalty if p.HasField("repetition_penalty") else 1.0
+                got = warp_row(
+                    z[f"{name}.{step}.logits"][b],
+                    temperature=(p.temperature or 1.0) if sampled else 1.0, top_k=p.top_k if sampled else 0,
+                    top_p_cut=float(np.float32(1) - np.float32(p.top_p)) if sampled and 0 < p.top_p < 1 else 0.0,
+                    typical_p=p.typical_p if sampled and 0 < p.typical_p < 1 else 1.0, rep_penalty=rep,
+                    input_ids=ids[b], exclude_id=2 if B != 1 else -1, eos_id=2, eos_mode=int(mode), eos_factor=factor)
+                want = z[f"{name}.{step}.scores"][b]
+                assert np.array_equal(np.isneginf(got), np.isneginf(want)), (name, step, b)
+                keep = ~np.isneginf(want)
+                np.testing.assert_allclose(got[keep], want[keep], rtol=1e-6, atol=1e-6)
