@@ -51,7 +51,7 @@ def _worker(rank, world, port, quantize, inter, ret, cfg_kw=None):
     from tgis_amd.models.flash_causal_lm import FlashCausalLM
     from tgis_amd.pb import generate_pb2 as pb2
 
-    cfg = TinyLlamaConfig(intermediate_size=inter, **(cfg_kw or {}))
+    cfg = TinyLlamaConfig(intermediate_size=inter, **{k: v for k, v in (cfg_kw or {}).items() if not k.startswith("_")})
     tensors = tiny_llama_tensors(cfg, seed=21, quantize=quantize, groupsize=64)
     tok = FixtureTokenizer(cfg.vocab_size)
     eng = InferenceEngine(tensors, LlamaConfig(**cfg.to_dict()), torch.float16, quantize, tokenizer=tok, gptq_groupsize=64)
@@ -67,6 +67,10 @@ def _worker(rank, world, port, quantize, inter, ret, cfg_kw=None):
     lm._process_new_tokens = tapped
     reqs = [pb2.Request(id=i, inputs=prompt_text(p), input_length=len(p), truncate=False, max_output_length=STEPS + 2)
             for i, p in enumerate(PROMPTS)]
+    if (cfg_kw or {}).get("_sample"):
+        # request 0 seeded, request 1 WITHOUT a seed (ranks must still agree), the rest greedy
+        reqs[0].parameters.temperature, reqs[0].parameters.top_k, reqs[0].parameters.seed = 0.9, 20, 7
+        reqs[1].parameters.temperature, reqs[1].parameters.top_p = 1.1, 0.9
     with lm.context_manager():
         batch, errs = lm.batch_type.from_pb(pb2.Batch(id=0, requests=reqs), tok, lm.dtype, lm.device, lm.word_embeddings,
                                             None, True)
@@ -219,3 +223,18 @@ def test_tp2_segmented_graphs_equal_eager(gpu_device, monkeypatch):
     assert ids_s == ids_e
     for a, b in zip(logits_s, logits_e):
         assert np.array_equal(a, b)
+
+
+def test_tp2_sampling_ranks_agree(gpu_device):
+    """Sampled requests under tensor parallelism: every rank draws the same tokens — with a request seed (same Philox
+    stream everywhere) and without one (rank 0's seed base is broadcast at start-up; seedless requests take
+    mix(base, arrival number))."""
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), "gptq", 512, ret, {"_sample": True}), nprocs=2, join=True)
+    ids0, logits0 = ret[0]
+    ids1, logits1 = ret[1]
+    assert ids0 == ids1
+    assert all(np.array_equal(a, b) for a, b in zip(logits0, logits1))
+    greedy = [[int(np.argmax(l[r])) for r in range(2, len(PROMPTS))] for l in logits0]
+    assert [row[2:] for row in ids0] == greedy  # the greedy neighbours are untouched by the sampled rows
