@@ -145,6 +145,13 @@ int tgis_rmsnorm_residual_partial(const float* slabs, int num_slabs, int64_t sla
 int tgis_layernorm_residual(const void* x, const void* residual, const void* weight, const void* bias,
                             void* y, void* res_out, int64_t rows, int64_t hidden, float eps,
                             int dtype, void* stream);
+/* tgis_layernorm_residual with x given as split-K partial sums (see tgis_rmsnorm_residual_partial): x = model-dtype
+ * rounding of sum_s slabs[s][row][:] (+ xbias, the producing linear's bias).  Removes the reduce launch after the
+ * c_proj linears of flash_santacoder_modeling.py:255-307. */
+int tgis_layernorm_residual_partial(const float* slabs, int num_slabs, int64_t slab_ld, const void* xbias,
+                                    const void* residual, const void* weight, const void* bias, void* y,
+                                    void* res_out, int64_t rows, int64_t hidden, float eps, int dtype,
+                                    void* stream);
 
 /* ---- RoPE + KV-cache write (replaces rotary_emb.apply_rotary + the index_put at
  *      flash_llama_modeling.py:262-268,282; utils/layers.py:466-472) ---------------------------- */

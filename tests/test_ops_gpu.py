@@ -387,6 +387,31 @@ def test_dense_partial_then_rmsnorm_is_bit_identical_to_unfused(nat, gpu_device,
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N", [(32, 6144, 6144), (5, 2048, 2048), (3, 256, 96), (64, 5632, 2048)])
+def test_dense_partial_then_layernorm_is_bit_identical_to_unfused(nat, gpu_device, dtype, M, K, N):
+    """GPT-BigCode's c_proj -> add + LayerNorm with the split-K sum (and the linear's bias) left to the norm kernel."""
+    g = torch.Generator().manual_seed(M + K + 1)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(dtype)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(dtype).to(gpu_device)
+    res = torch.randn(M, N, generator=g).to(dtype).to(gpu_device)
+    bias = (torch.randn(N, generator=g) * 0.1).to(dtype).to(gpu_device)
+    wn = (1 + 0.1 * torch.randn(N, generator=g)).to(dtype).to(gpu_device)
+    bn = (0.1 * torch.randn(N, generator=g)).to(dtype).to(gpu_device)
+    dw = nat.DenseWeight(w.to(gpu_device))
+    ws = nat.Workspace(dw.workspace_bytes(M), gpu_device)
+    y0, r0 = nat.layernorm_residual(nat.dense_gemm(x, dw, ws, bias=bias), res, wn, bn, 1e-5)
+    part = nat.dense_gemm_partial(x, dw, bias=bias)
+    if K >= 2048:
+        assert part.S > 1, "this shape is meant to exercise a real split"
+    y1, r1 = nat.layernorm_residual(part, res, wn, bn, 1e-5)
+    assert torch.equal(y0, y1) and torch.equal(r0, r1)
+    want_y, want_r = ops_ref.layernorm_residual(
+        (x.float().cpu() @ w.float().t() + bias.float().cpu()).to(dtype), res.cpu(), wn.cpu(), bn.cpu(), 1e-5)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    _close(r1, want_r, rtol=tol, atol=tol, what="partial + layernorm residual vs oracle")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("H,Hkv,D,rope", [(8, 8, 128, True), (8, 2, 64, True), (12, 1, 128, False)])
 def test_rope_kv_write_prefill_is_bit_identical_to_per_token_kernel(nat, gpu_device, dtype, H, Hkv, D, rope):
     """Page-wise prefill cache write == per-token kernel: rotated q rows, every valid cache slot, zeros in the tail of a

@@ -176,6 +176,15 @@ extern "C" int tgis_rmsnorm_residual_partial(const float* slabs, int num_slabs, 
                              num_slabs, slab_ld, bias);
 }
 
+extern "C" int tgis_layernorm_residual_partial(const float* slabs, int num_slabs, int64_t slab_ld, const void* xbias,
+                                               const void* residual, const void* weight, const void* bias, void* y,
+                                               void* res_out, int64_t rows, int64_t hidden, float eps, int dtype,
+                                               void* stream) {
+    TGIS_CHECK_ARG(slabs, "tgis_layernorm_residual_partial: null slabs");
+    return launch_norm<false>(nullptr, residual, weight, bias, y, res_out, rows, hidden, eps, dtype, stream, slabs,
+                              num_slabs, slab_ld, xbias);
+}
+
 extern "C" int tgis_layernorm_residual(const void* x, const void* residual, const void* weight,
                                        const void* bias, void* y, void* res_out, int64_t rows, int64_t hidden,
                                        float eps, int dtype, void* stream) {

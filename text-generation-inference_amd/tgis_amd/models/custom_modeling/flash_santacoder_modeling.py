@@ -121,7 +121,9 @@ class FlashMQAttention:
 
     def forward(self, hidden_states, position_ids, cu_seqlens_q, layer_id: int, kv: KVArgs):
         H, D = self.num_heads, self.head_size
-        qkv = self.c_attn(hidden_states)  # [T, (H + 2) D]: H query heads, then the single k and v heads
+        # [T, (H + 2) D]: H query heads, then the single k and v heads; at decode sizes the split-K sum is left to
+        # the cache-write kernel below (native.Partial)
+        qkv = self.c_attn(hidden_states, partial=True)
         k_pool, v_pool = kv.cache.k_pool(layer_id), kv.cache.v_pool(layer_id)
         if kv.fresh_prefill and not isinstance(qkv, native.Partial):
             qkv = native.rope_kv_write_prefill(qkv, None, None, None, cu_seqlens_q, kv.block_tables, k_pool, v_pool,
@@ -137,7 +139,7 @@ class FlashMQAttention:
         native.attn_paged(qkv, qkv.stride(0), k_pool, v_pool, kv.block_tables, kv.ctx_lens, cu_seqlens_q,
                           attn_output, kv.block_tables.shape[0], H, 1, D, kv.max_q_len, kv.max_ctx,
                           self.softmax_scale, kv.num_splits, ws)
-        return self.c_proj(attn_output)
+        return self.c_proj(attn_output, partial=True)  # summed by the following add + LayerNorm
 
     __call__ = forward
 
@@ -153,7 +155,7 @@ class MLP:
 
     def forward(self, hidden_states):
         h = self.c_fc(hidden_states)
-        return self.c_proj(native.gelu(h, self.tanh))
+        return self.c_proj(native.gelu(h, self.tanh), partial=True)  # summed by the next block's add + LayerNorm
 
     __call__ = forward
 

@@ -56,6 +56,8 @@ SIGNATURES = {
     "tgis_rmsnorm_residual_partial": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f,
                                                _c_int, _vp]),
     "tgis_layernorm_residual": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f, _c_int, _vp]),
+    "tgis_layernorm_residual_partial": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64,
+                                                 _c_f, _c_int, _vp]),
     "tgis_rope_kv_write": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_int, _c_int, _c_int,
                                     _c_int, _c_int, _vp]),
     "tgis_rope_kv_write_partial": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64,
@@ -378,6 +380,18 @@ def rmsnorm_residual(x, residual, weight, eps: float, y=None, res_out=None):
 
 def layernorm_residual(x, residual, weight, bias, eps: float, y=None, res_out=None):
     """(y, res) = fused add + LayerNorm; mirrors FastLayerNorm.forward (utils/layers.py:363-396)."""
+    if isinstance(x, Partial):
+        rows, hidden = x.shape
+        if y is None:
+            y = torch.empty((rows, hidden), dtype=x.dtype, device=x.device)
+        if res_out is None:
+            res_out = torch.empty_like(y)  # always materialised: it is the reduced (+residual) stream
+        _check(
+            load_library().tgis_layernorm_residual_partial(_ptr(x.slabs), x.S, x.ld, _ptr(x.bias), _ptr(residual),
+                                                           _ptr(weight), _ptr(bias), _ptr(y), _ptr(res_out), rows,
+                                                           hidden, float(eps), dtype_code(x.dtype), _stream()),
+            "tgis_layernorm_residual_partial")
+        return y, res_out
     assert x.dim() == 2 and x.is_contiguous()
     rows, hidden = x.shape
     if y is None:
