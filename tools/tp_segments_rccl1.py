@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--ctx", type=int, default=1024)
     ap.add_argument("--tp", type=int, default=1)
+    ap.add_argument("--config", default="llama2-7b-gptq")
     args = ap.parse_args()
     if args.tp > 1:
         os.environ.update(WORLD_SIZE=str(args.tp), RANK="0", TGIS_ALLOW_SHARED_GPU="1")
@@ -50,7 +51,7 @@ def main():
         torch.distributed.all_reduce = lambda t, group=None, **k: real_ar(t, group=pg, **k)
         # rank 0's block of the gathered logits + a launch of the same kind
         torch.distributed.all_gather_into_tensor = lambda o, i, group=None, **k: real_ag(o[:i.shape[0]], i, group=pg, **k)
-    kw, quantize, dtype_s, _, _ = bench.CONFIGS["llama2-7b-gptq"]
+    kw, quantize, dtype_s, _, _ = bench.CONFIGS[args.config]
     cfg = LlamaConfig(**kw)
     dtype = getattr(torch, dtype_s)
     B, K = args.batch, args.steps
