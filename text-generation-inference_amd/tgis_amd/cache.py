@@ -1,42 +1,47 @@
-"""Shard-side store of live batches between RPCs (mirrors cache.py:8-33 of the reference)."""
-from typing import Dict, List, Optional
+"""Shard-side store of the batches that stay alive between two RPCs.
+
+The servicer pops the batches a `NextToken` request names, works on them and puts the survivor back; `ClearCache`
+drops one or all of them (the contract of the reference's cache.py:8-33).  Batches of this engine own pages of the KV
+pool, so dropping one hands its pages back explicitly instead of waiting for the garbage collector."""
+from collections import OrderedDict
+from typing import List, Optional
 
 from tgis_amd.models.types import Batch
 
 
+def _give_back(batch) -> None:
+    release = getattr(batch, "release", None)  # contiguous-KV batch types have nothing to hand back
+    if callable(release):
+        release()
+
+
 class Cache:
     def __init__(self):
-        self.cache: Dict[int, Batch] = {}
-
-    def pop(self, batch_id: int) -> Optional[Batch]:
-        return self.cache.pop(batch_id, None)
-
-    def set(self, entry: Optional[Batch]):
-        if entry is not None:
-            self.cache[entry.batch_id] = entry
-
-    def delete(self, batch_id: int):
-        batch = self.cache.pop(batch_id)
-        _release(batch)
-
-    def clear(self):
-        for batch in self.cache.values():
-            _release(batch)
-        self.cache.clear()
-
-    def keys(self) -> List[int]:
-        return list(self.cache)
+        self.cache: "OrderedDict[int, Batch]" = OrderedDict()  # insertion order = age
 
     def __len__(self) -> int:
         return len(self.cache)
 
-    def compact(self):
-        for batch in self.cache.values():
+    def keys(self) -> List[int]:
+        return [bid for bid in self.cache]
+
+    def set(self, entry: Optional[Batch]) -> None:
+        if entry is None:
+            return
+        self.cache[entry.batch_id] = entry
+
+    def pop(self, batch_id: int) -> Optional[Batch]:
+        """The batch, now owned by the caller (None if the id is unknown)."""
+        return self.cache.pop(batch_id, None)
+
+    def delete(self, batch_id: int) -> None:
+        _give_back(self.cache.pop(batch_id))  # KeyError for an unknown id, as a dict would
+
+    def clear(self) -> None:
+        while self.cache:
+            _, batch = self.cache.popitem()
+            _give_back(batch)
+
+    def compact(self) -> None:
+        for batch in list(self.cache.values()):
             batch.compact()
-
-
-def _release(batch):
-    # paged-KV batches hand their pages back explicitly (a contiguous-KV batch just drops its tensors)
-    rel = getattr(batch, "release", None)
-    if rel is not None:
-        rel()
