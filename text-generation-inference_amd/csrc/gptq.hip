@@ -316,7 +316,9 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
     auto group_sync = [&](int target) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add((lds_int*)sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifndef ABL_NOSYNCWAIT  // ablation: arrive but never wait (wrong results; bounds what a slacker hand-off could gain)
         while (__builtin_amdgcn_readfirstlane(*sync_cnt) < target) __builtin_amdgcn_s_sleep(1);
+#endif
         asm volatile("" ::: "memory");
     };
     stage_store(0);
