@@ -403,7 +403,12 @@ class FlashCausalLM(Model):
     def resolve_graph_mode(self) -> str:
         """"full" or "segments"; `auto` is settled once, identically on every rank."""
         if self.graph_mode == "auto":
-            self.graph_mode = "full" if self._collective_capture_works() else "segments"
+            try:
+                works = self._collective_capture_works()
+            except Exception as exc:  # an unusable probe must not take the server down: segments need no capture of RCCL
+                logger.warning("probing RCCL graph capture failed (%s)", exc)
+                works = False
+            self.graph_mode = "full" if works else "segments"
             logger.info("tensor-parallel decode graphs: %s", self.graph_mode)
         return self.graph_mode
 
