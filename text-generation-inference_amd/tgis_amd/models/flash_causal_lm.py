@@ -325,8 +325,18 @@ class _DecodeGraph:
                 g = torch.cuda.CUDAGraph()
                 # tp > 1: RCCL's proxy and watchdog threads may call the runtime while this thread captures
                 kw = {"capture_error_mode": "thread_local"} if self.lm.tp_world > 1 else {}
-                with torch.cuda.graph(g, **kw):
-                    self.logits, self.ids, self.logprobs = self._step()
+                try:
+                    with torch.cuda.graph(g, **kw):
+                        self.logits, self.ids, self.logprobs = self._step()
+                except Exception as exc:
+                    if self.lm.tp_world == 1:
+                        raise
+                    # the probe passed but the whole step did not capture: the same failure on every rank, so every
+                    # rank takes the same way out — graphs between the collectives
+                    logger.warning("capturing the tensor-parallel step with RCCL inside failed (%s); using segments", exc)
+                    native.clear_error()
+                    self.lm.graph_mode = "segments"
+                    return self.run(input_ids, position_ids, block_tables)
             self.graph = g
         self.graph.replay()
         return self.logits, self.ids, self.logprobs
