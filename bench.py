@@ -166,6 +166,18 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
 
     from tgis_amd import native
+
+    if not os.path.exists(native.LIB_PATH):  # a checkout without built artefacts
+        if rank == 0:
+            import __graft_entry__
+
+            __graft_entry__.build()
+        if world > 1:
+            import time as _t
+
+            while not os.path.exists(native.LIB_PATH):  # the other ranks wait for rank 0's build
+                _t.sleep(1.0)
+            _t.sleep(2.0)
     from tgis_amd.inference_engine.synthetic import BigCodeConfig, InferenceEngine, bigcode_tensors, llama_tensors
     from tgis_amd.models.custom_modeling.flash_llama_modeling import LlamaConfig
     from tgis_amd.models.flash_causal_lm import FlashCausalLM

@@ -18,6 +18,12 @@ def pytest_configure(config):
 def gpu_device():
     import torch
 
+    lib = os.path.join(PKG, "lib", "libtgis_hip.so")
+    if not os.path.exists(lib):  # a checkout without built artefacts: compile once (hipcc is in the image)
+        import __graft_entry__
+
+        __graft_entry__.build()
+
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a GPU: torch.cuda.is_available() is False")
     return torch.device("cuda:0")
