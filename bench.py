@@ -160,9 +160,18 @@ def main():
     rank = int(os.getenv("RANK", "0"))
     world = int(os.getenv("WORLD_SIZE", "1"))
     os.environ.setdefault("TGIS_DIST_TIMEOUT_S", "600")  # cold boxes: first imports and weight set-up skew the ranks
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare (`python bench.py --gpus N`): become the launcher of N ranks, one per GPU, on this node
+        import socket
+
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port",
+                                  str(port), os.path.abspath(__file__), *sys.argv[1:]])
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
 
     from tgis_amd import native

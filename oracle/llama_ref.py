@@ -62,11 +62,22 @@ class LlamaRef:
         """Per sequence, per layer: K [t,Hkv,D] and V [t,Hkv,D] (rotated keys), grown by forward()."""
         return [[None] * self.L for _ in range(batch)]
 
+    @staticmethod
+    def _last_rows(seq_of_token: List[int]) -> List[int]:
+        """Index of the last token of every sequence (sequences are contiguous runs)."""
+        return [i for i in range(len(seq_of_token)) if i + 1 == len(seq_of_token) or seq_of_token[i + 1] != seq_of_token[i]]
+
     def forward(self, input_ids: torch.Tensor, position_ids: torch.Tensor, seq_of_token: List[int], state,
-                hidden_in: Optional[torch.Tensor] = None, return_hidden: bool = False) -> torch.Tensor:
+                hidden_in: Optional[torch.Tensor] = None, return_hidden: bool = False,
+                last_only: bool = False) -> torch.Tensor:
         """One forward over T tokens (any mix of prefill runs and decode tokens): token i belongs to sequence
         seq_of_token[i] at position position_ids[i]; tokens of one sequence are contiguous and ascending.
-        Returns fp32 logits [T, V] and appends this forward's K/V to `state`."""
+        Returns fp32 logits [T, V] and appends this forward's K/V to `state`.
+        last_only=True returns the logits of each sequence's last token only ([B, V], what generate_token consumes:
+        flash_causal_lm.py:515-521 `out[cu_seqlens[1:] - 1]`) and skips work nothing depends on: in the LAST layer the
+        queries, attention output, o_proj and MLP of the other tokens feed nothing (their K/V are still computed
+        and cached).  Same arithmetic for every value that is returned or cached; it only makes prompts of
+        workload length affordable on CPU."""
         T = len(seq_of_token)
         x = hidden_in if hidden_in is not None else self._vec("model.embed_tokens.weight")[input_ids.long()]
         max_pos = int(position_ids.max()) + 1
@@ -75,28 +86,40 @@ class LlamaRef:
         seqs = sorted(set(seq_of_token), key=seq_of_token.index)
         tok_idx = {b: [i for i, s in enumerate(seq_of_token) if s == b] for b in seqs}
         residual = None
+        keep = None
         for l in range(self.L):
             p = f"model.layers.{l}"
             h, residual = ops_ref.rmsnorm_residual(x, residual, self._vec(f"{p}.input_layernorm.weight"), self.eps)
-            q = (h @ self._lin(f"{p}.self_attn.q_proj")).view(T, self.H, self.D)
             k = (h @ self._lin(f"{p}.self_attn.k_proj")).view(T, self.Hkv, self.D)
             v = (h @ self._lin(f"{p}.self_attn.v_proj")).view(T, self.Hkv, self.D)
-            q = ops_ref.apply_rope(q, cos, sin)
             k = ops_ref.apply_rope(k, cos, sin)
-            attn = torch.empty((T, self.H, self.D), dtype=torch.float32)
+            if last_only and l == self.L - 1:
+                keep = self._last_rows(seq_of_token)
+            rows = keep if keep is not None else list(range(T))
+            hq = h[rows] if keep is not None else h
+            q = (hq @ self._lin(f"{p}.self_attn.q_proj")).view(len(rows), self.H, self.D)
+            q = ops_ref.apply_rope(q, cos[rows], sin[rows])
+            attn = torch.empty((len(rows), self.H, self.D), dtype=torch.float32)
+            row_of = {r: j for j, r in enumerate(rows)}
             for b in seqs:
                 idx = tok_idx[b]
                 past = state[b][l]
                 kb = k[idx] if past is None else torch.cat([past[0], k[idx]])
                 vb = v[idx] if past is None else torch.cat([past[1], v[idx]])
                 state[b][l] = (kb, vb)
-                attn[idx] = ops_ref.attention_varlen(q[idx], kb, vb, [0, len(idx)], [0, kb.shape[0]], self.D ** -0.5)
-            o = attn.reshape(T, self.H * self.D) @ self._lin(f"{p}.self_attn.o_proj")
+                qi = [row_of[i] for i in idx if i in row_of]  # the LAST len(qi) tokens of this run
+                attn[qi] = ops_ref.attention_varlen(q[qi], kb, vb, [0, len(qi)], [0, kb.shape[0]], self.D ** -0.5)
+            if keep is not None:
+                residual = residual[rows]
+            o = attn.reshape(len(rows), self.H * self.D) @ self._lin(f"{p}.self_attn.o_proj")
             h2, residual = ops_ref.rmsnorm_residual(o, residual, self._vec(f"{p}.post_attention_layernorm.weight"),
                                                     self.eps)
             gate = h2 @ self._lin(f"{p}.mlp.gate_proj")
             up = h2 @ self._lin(f"{p}.mlp.up_proj")
             x = (torch.nn.functional.silu(gate) * up) @ self._lin(f"{p}.mlp.down_proj")
+        if last_only and keep is None:  # no layers at all
+            keep = self._last_rows(seq_of_token)
+            x = x[keep]
         if return_hidden:
             return x if residual is None else x + residual
         hfin, _ = ops_ref.rmsnorm_residual(x, residual, self._vec("model.norm.weight"), self.eps)
@@ -110,12 +133,11 @@ class LlamaRef:
         `forced[step][b]` teacher-forces the token fed back (the oracle's own argmax otherwise)."""
         B = len(prompts)
         state = self.new_state(B)
+        self.last_state = state  # per sequence, per layer (K, V): tests read the cache contents back against it
         ids = torch.tensor([t for p in prompts for t in p], dtype=torch.int64)
         pos = torch.tensor([i for p in prompts for i in range(len(p))], dtype=torch.int64)
         seq = [b for b, p in enumerate(prompts) for _ in p]
-        logits = self.forward(ids, pos, seq, state)
-        last = np.cumsum([len(p) for p in prompts]) - 1
-        logits = logits[last]
+        logits = self.forward(ids, pos, seq, state, last_only=True)
         lengths = [len(p) for p in prompts]
         cu = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
         cu_q = np.arange(B + 1, dtype=np.int64)

@@ -1,0 +1,350 @@
+"""-m gpu: every BASELINE.json GPU config through the product path at WORKLOAD SIZE against the CPU oracle.
+
+One- or two-layer slices of cfg2 (TinyLlama-1.1B bf16), cfg3 (Llama-2-7B int4 GPTQ), cfg4 (Llama-2-70B int4 at TP=8
+shard shapes, eight ranks sharing the GPU) and cfg5 (Starcoder-15B bf16, MQA) at their real widths (E, I, H, Hkv, D,
+V), real batch (16 / 32 / 64 / 32) and real context (512 / 1024 / 2048 / 4096): the KV pages are filled by the
+product's own prefill, then decode steps run through the captured graph.  Compared with oracle/llama_ref.py /
+oracle/santacoder_ref.py on the same seeded tensors and prompts (teacher-forced with the product's ids):
+
+  * logits: max |product - oracle| <= LOGIT_TOL (stated per case, absolute, on logits of std ~1.3 / ~0.6);
+  * token ids: the product's ids are the exact argmax of its own logits, and equal the oracle's ids wherever the
+    oracle's top-2 margin exceeds 2 x LOGIT_TOL (random-init models have near-uniform logits, so a few rows per step
+    are closer than any fp16/bf16 pipeline can resolve; their count is asserted small and printed);
+  * logical KV slot indices cu_seqlens[1:] - 1: bit-exact every step;
+  * cache contents of the first and last sequence after prefill + decode: K/V read back from the pages vs the
+    oracle's K/V (checks the page-wise prefill writer, RoPE at D = 64 / 128 and the decode scatter at width).
+
+The oracle skips work nothing depends on (LlamaRef.forward(last_only=True)): in the last layer only each sequence's
+final token needs q / attention / MLP during prefill, which is what makes 32 x 1024 ... 32 x 4096 prompt tokens
+affordable in fp32 on the host."""
+import os
+import socket
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import ops_ref
+from oracle.llama_ref import LlamaRef
+from oracle.santacoder_ref import SantacoderRef
+
+pytestmark = pytest.mark.gpu
+
+LLAMA_7B = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_attention_heads=32,
+                num_key_value_heads=32, rms_norm_eps=1e-5)
+TINYLLAMA = dict(vocab_size=32000, hidden_size=2048, intermediate_size=5632, num_attention_heads=32,
+                 num_key_value_heads=4, rms_norm_eps=1e-5)
+LLAMA_70B = dict(vocab_size=32000, hidden_size=8192, intermediate_size=28672, num_attention_heads=64,
+                 num_key_value_heads=8, rms_norm_eps=1e-5)
+STARCODER = dict(vocab_size=49152, hidden_size=6144, n_inner=24576, num_attention_heads=48, n_positions=8192)
+
+# name: (family, config kwargs, layers, quantize, dtype, batch, prompt length, decode steps, logit tolerance)
+# Context seen by the decode steps = prompt length + 1 ... + steps, i.e. it straddles the config's nominal context.
+# LOGIT_TOL: the product rounds activations to fp16 (2^-11) / bf16 (2^-8) after every kernel (about eight roundings per
+# layer) and P to the model dtype inside attention; logits have std ~1.3 (llama, lm_head std 0.02 x sqrt(E) after a
+# unit-RMS norm).  Measured maxima on MI355X are noted per case; the bound is ~2.5x the measurement.
+CASES = {
+    "cfg2-tinyllama-bf16-b16-ctx512": ("llama", TINYLLAMA, 2, None, torch.bfloat16, 16, 509, 4, 0.12),
+    "cfg3-llama7b-gptq-b32-ctx1024": ("llama", LLAMA_7B, 1, "gptq", torch.float16, 32, 1021, 4, 0.02),
+    "cfg3-llama7b-gptq-2layer-b4-ctx1024": ("llama", LLAMA_7B, 2, "gptq", torch.float16, 4, 1021, 4, 0.02),
+    "cfg5-starcoder-bf16-b32-ctx4096": ("bigcode", STARCODER, 1, None, torch.bfloat16, 32, 4093, 4, 0.12),
+}
+MAX_TIE_ROWS_FRAC = 0.15  # rows per step the oracle itself decides by less than 2 x LOGIT_TOL
+
+
+def _prompts(B, L, V, seed):
+    rng = np.random.default_rng(seed)
+    return [rng.integers(3, V, size=L).tolist() for _ in range(B)]
+
+
+def _make(family, kw, layers, quantize, dtype, seed):
+    """(product config, oracle config, seeded CPU tensors).  One recipe for both sides: tgis_amd's synthetic
+    generator (SURVEY §8d weights) — the oracle reads the very same tensors."""
+    from tgis_amd.inference_engine.synthetic import BigCodeConfig, bigcode_tensors, llama_tensors
+    from tgis_amd.models.custom_modeling.flash_llama_modeling import LlamaConfig
+
+    if family == "llama":
+        cfg = LlamaConfig(num_hidden_layers=layers, max_position_embeddings=4096, **kw)
+        tensors = llama_tensors(cfg, quantize, seed=seed, device="cpu", dtype=dtype)
+    else:
+        cfg = BigCodeConfig(num_hidden_layers=layers, **kw)
+        tensors = bigcode_tensors(cfg, seed=seed, device="cpu", dtype=dtype)
+    return cfg, tensors
+
+
+def _oracle(family, cfg, tensors, quantize):
+    if family == "llama":
+        return LlamaRef(cfg, tensors, quantize=quantize, groupsize=128)
+    return SantacoderRef(cfg, tensors)
+
+
+def _pb(prompts, max_new):
+    from tests.fixture_utils import prompt_text
+    from tgis_amd.pb import generate_pb2 as pb2
+
+    reqs = []
+    for i, p in enumerate(prompts):
+        r = pb2.Request(id=i, inputs=prompt_text(p), input_length=len(p), truncate=False, max_output_length=max_new)
+        r.details.logprobs = True
+        reqs.append(r)
+    return pb2.Batch(id=0, requests=reqs)
+
+
+def _run_product(lm, tok, prompts, steps):
+    """Prefill + (steps - 1) decode steps.  Returns per step (ids, fp32 logits, logprobs, logical slot indices)."""
+    rows = {}
+    orig = lm._process_new_tokens
+
+    def tapped(batch, out, *a, **kw):
+        rows["logits"] = out.detach().float().cpu().numpy().copy()
+        return orig(batch, out, *a, **kw)
+
+    lm._process_new_tokens = tapped
+    got = []
+    with lm.context_manager():
+        batch, errs = lm.batch_type.from_pb(_pb(prompts, steps + 2), tok, lm.dtype, lm.device, lm.word_embeddings, None,
+                                            True)
+        assert not errs
+        for i in range(steps):
+            toks, _in, errs, _ns = lm.generate_token(batch, first=(i == 0))
+            assert not errs
+            slots = (batch.cu_seqlens[1:] - 1).cpu().numpy().copy()
+            got.append(([t.token_id for t in toks], rows["logits"], [t.logprob for t in toks], slots))
+    return batch, got
+
+
+def _compare(name, got, want, tol, B):
+    worst, ties = 0.0, 0
+    for i, ((ids, logits, lps, slots), w) in enumerate(zip(got, want)):
+        wl = w["logits"].numpy()
+        err = float(np.abs(logits - wl).max())
+        worst = max(worst, err)
+        assert err <= tol, f"{name} step {i}: max |logit - oracle| = {err:.4f} > {tol}"
+        assert ids == np.argmax(logits, axis=1).tolist(), f"{name} step {i}: ids are not the argmax of the product logits"
+        assert slots.tolist() == w["slot_indices"].tolist(), f"{name} step {i}: logical KV slot indices"
+        wid = w["token_ids"].tolist()
+        step_ties = 0
+        for r in range(B):
+            if ids[r] != wid[r]:
+                gap = float(wl[r, wid[r]] - wl[r, ids[r]])
+                assert gap <= 2 * tol, (f"{name} step {i} row {r}: token {ids[r]} != oracle {wid[r]} although the oracle "
+                                        f"prefers it by {gap:.4f} > 2 x {tol}")
+                step_ties += 1
+        ties += step_ties
+        assert step_ties <= max(1, int(MAX_TIE_ROWS_FRAC * B)), f"{name} step {i}: {step_ties} of {B} rows flipped"
+        same = [a == b for a, b in zip(ids, wid)]
+        np.testing.assert_allclose(np.array(lps)[same], w["logprobs"].numpy()[same], atol=2 * tol,
+                                   err_msg=f"{name} step {i}: logprobs")
+    print(f"\n[{name}] max |logit - oracle| = {worst:.4f} (bound {tol}); rows decided inside 2 x tol: {ties} of "
+          f"{B * len(got)}")
+    return worst, ties
+
+
+def _check_cache(name, lm, batch, ref_state, seqs, Hkv, D, dtype):
+    """K/V of the given sequences (layer 0) read back from the pages vs the oracle's cached K/V."""
+    tol = 0.02 if dtype == torch.float16 else 0.12
+    k_pool, v_pool = lm.kv_cache.k_pool(0).float().cpu(), lm.kv_cache.v_pool(0).float().cpu()
+    for b in seqs:
+        kb, vb = ref_state[b][0]
+        n = kb.shape[0]
+        K = torch.cat([ops_ref.kv_page_unpack(k_pool, v_pool, pg, Hkv, D)[0] for pg in batch.pages[b]])[:n]
+        V = torch.cat([ops_ref.kv_page_unpack(k_pool, v_pool, pg, Hkv, D)[1] for pg in batch.pages[b]])[:n]
+        ek, ev = float((K - kb).abs().max()), float((V - vb).abs().max())
+        assert ek <= tol * max(1.0, float(kb.abs().max())), f"{name}: cached K of sequence {b} off by {ek:.4f}"
+        assert ev <= tol * max(1.0, float(vb.abs().max())), f"{name}: cached V of sequence {b} off by {ev:.4f}"
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_full_width_slice_matches_oracle(gpu_device, name):
+    from tests.fixture_utils import FixtureTokenizer
+    from tgis_amd.inference_engine.synthetic import InferenceEngine
+    from tgis_amd.models.flash_causal_lm import FlashCausalLM
+    from tgis_amd.utils.kv_cache import PagedKVCache
+
+    family, kw, layers, quantize, dtype, B, L, steps, tol = CASES[name]
+    cfg, tensors = _make(family, kw, layers, quantize, dtype, seed=4321)
+    prompts = _prompts(B, L, cfg.vocab_size, seed=99)
+    tok = FixtureTokenizer(cfg.vocab_size)
+    eng = InferenceEngine({k: v.clone() for k, v in tensors.items()}, cfg, dtype, quantize, tokenizer=tok)
+    pages = B * PagedKVCache.pages_for(L + steps + 2) + 8
+    lm = FlashCausalLM("fullwidth", None, "synthetic", dtype, quantize, engine=eng, kv_cache_pages=pages)
+    assert lm.use_graphs
+    t0 = time.time()
+    batch, got = _run_product(lm, tok, prompts, steps)
+    torch.cuda.synchronize()
+    t1 = time.time()
+    ref = _oracle(family, cfg, tensors, quantize)
+    want = ref.generate_greedy(prompts, steps, forced=[g[0] for g in got])
+    t2 = time.time()
+    print(f"\n[{name}] product {t1 - t0:.1f} s, oracle {t2 - t1:.1f} s")
+    _compare(name, got, want, tol, B)
+    # the oracle's state after generate_greedy holds prompt + (steps - 1) fed tokens; the product has written the same
+    Hkv = 1 if family == "bigcode" else cfg.num_key_value_heads
+    D = cfg.hidden_size // cfg.num_attention_heads
+    _check_cache(name, lm, batch, ref.last_state, [0, B - 1], Hkv, D, dtype)
+    batch.release()
+    assert lm.kv_cache.free_pages == lm.kv_cache.num_pages, "pages leaked"
+
+
+# ---- cfg4: Llama-2-70B at TP=8 shard shapes -------------------------------------------------------------------------
+# Eight ranks share the one GPU (collectives through gloo, as in tests/test_tp_gpu.py): every rank runs the shipped
+# kernels on its real shard — qkv 8192 x 1280, o 1024 x 8192, gate_up 8192 x 7168, down 3584 x 8192 (int4, g128; the
+# row-parallel shards regroup 28 groups per rank), one kv head and eight q heads per rank (GQA 8:1) at ctx 2048, B = 64,
+# vocab-parallel embedding and head — and the gathered logits are compared with the unsharded oracle.
+CFG4 = ("cfg4-llama70b-gptq-tp8-b64-ctx2048", LLAMA_70B, 1, "gptq", torch.float16, 64, 2045, 4, 0.03)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tp_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      TGIS_DIST_BACKEND="gloo", TGIS_ALLOW_SHARED_GPU="1", TGIS_DIST_TIMEOUT_S="900")
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "text-generation-inference_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from tests.fixture_utils import FixtureTokenizer
+    from tests.test_fullwidth_gpu import CFG4, _make, _prompts, _run_product
+    from tgis_amd.inference_engine.synthetic import InferenceEngine
+    from tgis_amd.models.flash_causal_lm import FlashCausalLM
+    from tgis_amd.utils.kv_cache import PagedKVCache
+
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
+    name, kw, layers, quantize, dtype, B, L, steps, tol = CFG4
+    cfg, tensors = _make("llama", kw, layers, quantize, dtype, seed=4321)
+    prompts = _prompts(B, L, cfg.vocab_size, seed=99)
+    tok = FixtureTokenizer(cfg.vocab_size)
+    eng = InferenceEngine(tensors, cfg, dtype, quantize, tokenizer=tok)
+    assert eng.world_size == world
+    del tensors
+    pages = B * PagedKVCache.pages_for(L + steps + 2) + 8
+    lm = FlashCausalLM("fullwidth-tp", None, "synthetic", dtype, quantize, engine=eng, kv_cache_pages=pages)
+    shard_shapes = sorted({(lin.height, lin.width) for lin in lm.model.gptq_linears})
+    batch, got = _run_product(lm, tok, prompts, steps)
+    batch.release()
+    if rank == 0:
+        ret["got"] = [(ids, logits, lps, slots) for ids, logits, lps, slots in got]
+        ret["shapes"] = shard_shapes
+        ret["heads"] = (lm.num_heads, lm.num_kv_heads)
+    else:
+        ret[f"ids{rank}"] = [g[0] for g in got]
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_cfg4_tp8_shard_shapes_match_oracle(gpu_device):
+    name, kw, layers, quantize, dtype, B, L, steps, tol = CFG4
+    mgr = mp.get_context("spawn").Manager()  # never fork a process that has run gRPC (or CUDA) threads
+    ret = mgr.dict()
+    t0 = time.time()
+    mp.spawn(_tp_worker, args=(8, _free_port(), ret), nprocs=8, join=True)
+    t1 = time.time()
+    got = ret["got"]
+    assert ret["shapes"] == [(1024, 8192), (3584, 8192), (8192, 1280), (8192, 7168)], ret["shapes"]
+    assert ret["heads"] == (8, 1)
+    for r in range(1, 8):
+        assert ret[f"ids{r}"] == [g[0] for g in got], "ranks must stay in lock-step without a broadcast"
+    cfg, tensors = _make("llama", kw, layers, quantize, dtype, seed=4321)
+    prompts = _prompts(B, L, cfg.vocab_size, seed=99)
+    ref = LlamaRef(cfg, tensors, quantize=quantize, groupsize=128)
+    want = ref.generate_greedy(prompts, steps, forced=[g[0] for g in got])
+    print(f"\n[{name}] 8 ranks {t1 - t0:.1f} s, oracle {time.time() - t1:.1f} s")
+    _compare(name, got, want, tol, B)
+
+
+# ---- op level at the sizes the model slices above do not reach ------------------------------------------------------
+@pytest.mark.parametrize("K,N,M", [
+    (8192, 10240, 64), (8192, 8192, 64), (8192, 57344, 32), (28672, 8192, 64),  # Llama-2-70B, whole matrices
+    (8192, 1280, 64), (1024, 8192, 64), (8192, 7168, 64), (3584, 8192, 64),      # ... its TP=8 shards at B = 64
+    (8192, 7168, 32), (3584, 8192, 32),
+])
+def test_gptq_gemm_70b_shapes(gpu_device, K, N, M):
+    from tgis_amd import native
+
+    qw, qz, sc, gi = ops_ref.make_gptq_tensors(K, N, 128, seed=K + N + M)
+    dev = gpu_device
+    w = native.GptqWeight(torch.from_numpy(qw).to(dev), torch.from_numpy(qz).to(dev), torch.from_numpy(sc).to(dev),
+                          torch.from_numpy(gi), 4, 128)
+    x = (torch.randn(M, K, generator=torch.Generator().manual_seed(1)) * 0.5).half()
+    ws = native.Workspace(64 << 20, dev)
+    out = native.gptq_gemm(x.to(dev), w, ws).float().cpu()
+    want = x.float() @ ops_ref.gptq_dequant(qw, qz, sc, gi, 128)
+    # fp32 accumulation of K products of f16-rounded weights; output rounded to f16: |y| ~ 0.5 * 0.02 * sqrt(K) * 4
+    scale = float(want.abs().max())
+    err = float((out - want).abs().max())
+    assert err <= 2e-3 * scale + 1e-3, f"{K}x{N} M={M}: max err {err:.5f} (|y| max {scale:.3f})"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16])
+@pytest.mark.parametrize("N,K,M", [(6400, 6144, 32), (6144, 6144, 32), (24576, 6144, 32), (6144, 24576, 32),
+                                   (49152, 6144, 32), (2560, 2048, 16), (11264, 2048, 16), (2048, 5632, 16)])
+def test_dense_gemm_starcoder_tinyllama_shapes(gpu_device, dtype, N, K, M):
+    from tgis_amd import native
+
+    g = torch.Generator().manual_seed(N + K)
+    wt = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype)
+    x = torch.randn(M, K, generator=g).to(dtype)
+    w = native.DenseWeight(wt.to(gpu_device))
+    ws = native.Workspace(64 << 20, gpu_device)
+    out = native.dense_gemm(x.to(gpu_device), w, ws, out_f32=True).cpu()
+    want = x.float() @ wt.float().t()
+    err = float((out - want).abs().max())
+    assert err <= 2e-3 * float(want.abs().max()) + 1e-3, f"{N}x{K} M={M}: {err}"
+
+
+@pytest.mark.parametrize("name,B,H,Hkv,D,ctx,dtype", [
+    ("cfg4 GQA 8:1, one kv head per rank", 64, 8, 1, 128, 2048, torch.float16),
+    ("cfg4 GQA 8:1 unsharded", 16, 64, 8, 128, 2048, torch.float16),
+    ("cfg5 MQA 48:1 (three 16-head chunks)", 32, 48, 1, 128, 4096, torch.bfloat16),
+    ("cfg5 MQA 12:1 (TP=4 rank)", 32, 12, 1, 128, 4096, torch.bfloat16),
+    ("cfg2 GQA 8:1 D=64", 16, 32, 4, 64, 512, torch.bfloat16),
+])
+def test_decode_attention_at_workload_context(gpu_device, name, B, H, Hkv, D, ctx, dtype):
+    """Decode attention alone at the configs' batch x context (ragged around ctx), K/V written by the product's own
+    decode-form cache writer, against the fp32 oracle."""
+    from tgis_amd import native
+    from tgis_amd.utils.kv_cache import PAGE, PagedKVCache
+
+    dev = gpu_device
+    g = torch.Generator().manual_seed(B * H + ctx)
+    lens = [ctx - (7 * b) % 41 for b in range(B)]
+    cache = PagedKVCache(1, Hkv, D, sum(PagedKVCache.pages_for(l) for l in lens) + 4, dtype, dev)
+    pages = [cache.alloc(PagedKVCache.pages_for(l)) for l in lens]
+    width = (max(len(p) for p in pages) + 7) // 8 * 8
+    bt = np.zeros((B, width), dtype=np.int32)
+    for b, p in enumerate(pages):
+        bt[b, :len(p)] = p
+    bt = torch.from_numpy(bt).to(dev)
+    Ks = [torch.randn(l, Hkv, D, generator=g).to(dtype) for l in lens]
+    Vs = [torch.randn(l, Hkv, D, generator=g).to(dtype) for l in lens]
+    # fill the pages token by token through the decode-form writer (no rotation)
+    T = sum(lens)
+    kv = torch.zeros(T, (H + 2 * Hkv) * D, dtype=dtype)
+    kv[:, H * D:(H + Hkv) * D] = torch.cat(Ks).reshape(T, Hkv * D)
+    kv[:, (H + Hkv) * D:] = torch.cat(Vs).reshape(T, Hkv * D)
+    slots = np.concatenate([np.asarray(p, dtype=np.int64)[np.arange(l) // PAGE] * PAGE + np.arange(l) % PAGE
+                            for p, l in zip(pages, lens)]).astype(np.int32)
+    native.rope_kv_write(kv.to(dev), None, None, None, torch.from_numpy(slots).to(dev), cache.k_pool(0), cache.v_pool(0),
+                         H, Hkv, D, D)
+    q = torch.randn(B, H * D, generator=g).to(dtype)
+    out = torch.empty(B, H * D, dtype=dtype, device=dev)
+    ns = native.attn_num_splits(B, Hkv, H, 1, max(lens))
+    ws = native.Workspace(max(4096, native.attn_workspace_bytes(B, H, D, ns)), dev)
+    native.attn_paged(q.to(dev), H * D, cache.k_pool(0), cache.v_pool(0), bt,
+                      torch.tensor(lens, dtype=torch.int32, device=dev), torch.arange(B + 1, dtype=torch.int32, device=dev),
+                      out, B, H, Hkv, D, 1, max(lens), D ** -0.5, ns, ws if ns > 1 else None)
+    want = torch.cat([ops_ref.attention_varlen(q[b:b + 1].float().view(1, H, D), Ks[b].float(), Vs[b].float(), [0, 1],
+                                               [0, lens[b]], D ** -0.5) for b in range(B)]).reshape(B, H * D)
+    err = float((out.float().cpu() - want).abs().max())
+    tol = 4e-3 if dtype == torch.float16 else 2.5e-2  # outputs are averages of unit normals (|o| < 0.3): P and O rounding
+    assert err <= tol, f"{name}: max err {err:.5f} > {tol} (splits {ns})"

@@ -362,3 +362,54 @@ def test_batch_larger_than_one_row_slab_matches_oracle(gpu_device, variant):
             history[-1][t.request_id] = t.token_id
     batch.release()
     assert lm.kv_cache.free_pages == lm.kv_cache.num_pages, "pages leaked"
+
+
+def test_captured_graphs_survive_table_and_workspace_growth(gpu_device):
+    """Decode graphs hold raw device pointers to the rope tables and to the shared workspace.  Capture a short-context
+    graph, then serve a 2100-token request (rope tables grow past their first 2048 positions) and grow the workspace,
+    trample whatever the allocator got back, and replay the first graph: its logits must equal the eager step's bit
+    for bit (a freed table or workspace would make them garbage)."""
+    from tgis_amd.utils import layers as L
+
+    cfg = TinyLlamaConfig(max_position_embeddings=512)
+    tensors = tiny_llama_tensors(cfg, seed=5, quantize="gptq", groupsize=64)
+    lm, tok = _build(cfg, tensors, "gptq", 64, torch.float16, use_graphs=True)
+    rng = np.random.default_rng(23)
+    short = [rng.integers(3, cfg.vocab_size, size=n).tolist() for n in (40, 17)]
+    long_prompt = [rng.integers(3, cfg.vocab_size, size=2100).tolist()]
+
+    def run(prompts, n_steps, between=None):
+        tap = _LogitTap(lm)
+        batch = _from_pb(lm, tok, _pb(prompts, n_steps + 2))
+        out = []
+        for i in range(n_steps):
+            if between is not None and i == 2:
+                between()
+            out.append(_step(lm, batch, tap, first=(i == 0))[1])
+        batch.release()
+        return out
+
+    def disturb():
+        tables_before = lm.model.model.layers[0].self_attn.rotary_emb._cos_cached.data_ptr()
+        b = _from_pb(lm, tok, _pb(long_prompt, 4, first_id=10, batch_id=9))
+        tap = _LogitTap(lm)
+        _step(lm, b, tap, first=True)
+        _step(lm, b, tap)
+        b.release()
+        assert lm.model.model.layers[0].self_attn.rotary_emb._cos_cached.data_ptr() != tables_before, "tables did not grow"
+        ws = L.workspace(lm.device)
+        old = ws.ptr
+        ws.ensure(ws.nbytes * 2)
+        assert ws.ptr != old and ws.retired, "the replaced workspace must stay allocated"
+        torch.cuda.synchronize()
+        junk = [torch.full((1 << 22,), float("nan"), dtype=torch.float16, device=lm.device) for _ in range(24)]
+        torch.cuda.synchronize()
+        del junk
+
+    graphed = run(short, 5, between=disturb)
+    assert (2, 8) in lm._graphs and lm._graphs[(2, 8)].graph is not None
+    lm.use_graphs = False
+    eager = run(short, 5)
+    for i, (a, b) in enumerate(zip(graphed, eager)):
+        assert np.array_equal(a, b), f"step {i}: replayed graph differs from the eager step"
+    assert lm.kv_cache.free_pages == lm.kv_cache.num_pages

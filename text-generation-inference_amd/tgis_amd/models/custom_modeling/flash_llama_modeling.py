@@ -213,9 +213,12 @@ class FlashLlamaModel:
         self.max_positions = 0
 
     def rope_tables(self, dtype, device, max_s: int):
-        # grown geometrically so that captured decode graphs keep valid table pointers
+        # Sized once for the model's whole position range, so the tables normally never move.  A longer request
+        # still works: PositionRotaryEmbedding keeps the replaced tables allocated, because decode graphs captured
+        # earlier hold their raw pointers (and only ever index positions inside the table they captured).
         if max_s > self.max_positions:
-            self.max_positions = max(max_s, 2 * self.max_positions, 2048)
+            declared = min(int(getattr(self.config, "max_position_embeddings", 0) or 0), 1 << 17)
+            self.max_positions = max(max_s, 2 * self.max_positions, declared, 2048)
         return self.layers[0].self_attn.rotary_emb.tables(dtype, device, self.max_positions)
 
     def forward(self, input_ids, position_ids, cu_seqlens_q, max_s, inputs_embeds, kv: KVArgs):

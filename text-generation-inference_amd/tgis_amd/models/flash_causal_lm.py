@@ -17,6 +17,7 @@ What is different by design:
 import logging
 import os
 import time
+from collections import OrderedDict
 from dataclasses import dataclass
 from operator import itemgetter
 from typing import Any, List, Optional, Tuple, Type, Union
@@ -206,10 +207,9 @@ class FlashCausalLMBatch(Batch):
             cu_seqlens.append(batch.cu_seqlens[1:] + cumulative_length)
             input_ids.append(batch.input_ids)
             position_ids.append(batch.position_ids)
-            # page ownership moves to the merged batch; no KV bytes move (reference: torch.cat of the pasts)
+            # no KV bytes move (reference: torch.cat of the pasts); ownership of the pages changes hands below, once
+            # the merged batch exists — an exception before that leaves every page with its source batch
             pages.extend(batch.pages)
-            batch.pages = None
-            batch.block_tables = None
             end = start + len(batch)
             all_input_ids_tensor[start:end, :batch.all_input_ids_tensor.shape[1]] = batch.all_input_ids_tensor
             start = end
@@ -229,8 +229,16 @@ class FlashCausalLMBatch(Batch):
             max_seqlen=max_seqlen, past_key_values=None, input_lengths=input_lengths,
             total_lengths=total_lengths, all_input_ids_tensor=all_input_ids_tensor,
             next_token_chooser=next_token_chooser, pad_token_id=first.pad_token_id,
-            kv_cache=first.kv_cache, pages=pages)
-        merged._rebuild_block_tables()
+            kv_cache=first.kv_cache, pages=None)
+        merged.pages = pages
+        try:
+            merged._rebuild_block_tables()
+        except BaseException:
+            merged.pages = None  # the sources still own them
+            raise
+        for batch in batches:
+            batch.pages = None
+            batch.block_tables = None
         return merged
 
     @classmethod
@@ -311,9 +319,28 @@ class _DecodeGraph:
             # the capture
             self._step()
             torch.cuda.current_stream().synchronize()
-            mode = self.lm.resolve_graph_mode()
-            if mode == "segments":
-                g = SegmentedGraph(self.lm.device)
+            g = None
+            if self.lm.resolve_graph_mode() == "full":
+                g = torch.cuda.CUDAGraph()
+                # tp > 1: RCCL's proxy and watchdog threads may call the runtime while this thread captures
+                kw = {"capture_error_mode": "thread_local"} if self.lm.tp_world > 1 else {}
+                ok = True
+                try:
+                    with torch.cuda.graph(g, pool=self.lm.graph_pool, **kw):
+                        self.logits, self.ids, self.logprobs = self._step()
+                except Exception as exc:
+                    if self.lm.tp_world == 1:
+                        raise
+                    logger.warning("capturing the tensor-parallel step with RCCL inside failed (%s)", exc)
+                    native.clear_error()
+                    ok = False
+                if self.lm.tp_world > 1 and not self.lm.all_ranks_agree(ok):
+                    # one rank failing is every rank's failure: all of them leave `full` together, or their collective
+                    # sequences would diverge (a capture issues no collective, so nobody is waiting inside one here)
+                    self.lm.graph_mode = "segments"
+                    g = None
+            if g is None:
+                g = SegmentedGraph(self.lm.device, pool=self.lm.graph_pool)
                 try:
                     self.logits, self.ids, self.logprobs = g.record(self._step)
                 except Exception as exc:  # keep serving: the eager step needs nothing the capture set up
@@ -321,22 +348,6 @@ class _DecodeGraph:
                     native.clear_error()
                     self.lm.use_graphs = False
                     return self._step()
-            else:
-                g = torch.cuda.CUDAGraph()
-                # tp > 1: RCCL's proxy and watchdog threads may call the runtime while this thread captures
-                kw = {"capture_error_mode": "thread_local"} if self.lm.tp_world > 1 else {}
-                try:
-                    with torch.cuda.graph(g, **kw):
-                        self.logits, self.ids, self.logprobs = self._step()
-                except Exception as exc:
-                    if self.lm.tp_world == 1:
-                        raise
-                    # the probe passed but the whole step did not capture: the same failure on every rank, so every
-                    # rank takes the same way out — graphs between the collectives
-                    logger.warning("capturing the tensor-parallel step with RCCL inside failed (%s); using segments", exc)
-                    native.clear_error()
-                    self.lm.graph_mode = "segments"
-                    return self.run(input_ids, position_ids, block_tables)
             self.graph = g
         self.graph.replay()
         return self.logits, self.ids, self.logprobs
@@ -408,7 +419,11 @@ class FlashCausalLM(Model):
             torch.distributed.broadcast(t, src=0, group=self.process_group)
             hi, lo = t.tolist()
             tokens.set_seed_base((hi << 32) | lo)
-        self._graphs = {}
+        # captured decode steps, least recently used first; they share one memory pool (a step's intermediates are dead
+        # once it has run, and its outputs are consumed before the next replay), and the number kept is bounded
+        self._graphs = OrderedDict()
+        self.max_graphs = int(os.getenv("TGIS_MAX_DECODE_GRAPHS", "48"))
+        self.graph_pool = torch.cuda.graph_pool_handle() if self.use_graphs else None
 
     def resolve_graph_mode(self) -> str:
         """"full" or "segments"; `auto` is settled once, identically on every rank."""
@@ -421,6 +436,16 @@ class FlashCausalLM(Model):
             self.graph_mode = "full" if works else "segments"
             logger.info("tensor-parallel decode graphs: %s", self.graph_mode)
         return self.graph_mode
+
+    def all_ranks_agree(self, ok: bool) -> bool:
+        """True iff `ok` holds on every rank of the tensor-parallel group (one small all-reduce, outside any capture)."""
+        pg = self.process_group
+        if self.tp_world == 1 or not isinstance(pg, torch.distributed.ProcessGroup):
+            return ok
+        dev = self.device if torch.distributed.get_backend(pg) == "nccl" else "cpu"
+        flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=pg)
+        return bool(flag.item())
 
     def _collective_capture_works(self) -> bool:
         pg = self.process_group
@@ -499,7 +524,11 @@ class FlashCausalLM(Model):
         key = (len(batch), batch.block_tables.shape[1])
         g = self._graphs.get(key)
         if g is None:
+            while len(self._graphs) >= self.max_graphs:
+                self._graphs.popitem(last=False)
             g = self._graphs[key] = _DecodeGraph(self, *key)
+        else:
+            self._graphs.move_to_end(key)
         logits, ids, lps = g.run(batch.input_ids, batch.position_ids, batch.block_tables)
         return logits, (ids, lps)
 

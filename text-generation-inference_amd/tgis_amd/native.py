@@ -165,10 +165,15 @@ class Workspace:
 
     def __init__(self, nbytes: int, device):
         self.buf = torch.zeros(max(int(nbytes), 4096), dtype=torch.uint8, device=device)
+        # Buffers replaced by larger ones stay allocated: HIP graphs captured while they were current hold their raw
+        # pointers (slabs, arrival counters, attention splits).  Each buffer's counters are only ever touched by the
+        # launches that captured it, so old graphs and new launches never share state.
+        self.retired = []
 
     def ensure(self, nbytes: int):
         if self.buf.numel() < nbytes:
-            self.buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.buf.device)
+            self.retired.append(self.buf)
+            self.buf = torch.zeros(max(int(nbytes), 2 * self.buf.numel()), dtype=torch.uint8, device=self.buf.device)
 
     @property
     def ptr(self):

@@ -25,9 +25,9 @@ def collective(fn: Callable[[], None]) -> None:
 
 
 class SegmentedGraph:
-    def __init__(self, device: torch.device):
+    def __init__(self, device: torch.device, pool=None):
         self.device = device
-        self.pool = torch.cuda.graph_pool_handle()
+        self.pool = pool if pool is not None else torch.cuda.graph_pool_handle()
         self.stream = torch.cuda.Stream(device)
         self.items: List[Union[torch.cuda.CUDAGraph, Callable[[], None]]] = []
         self._open: Optional[torch.cuda.CUDAGraph] = None

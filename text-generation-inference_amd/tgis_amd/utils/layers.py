@@ -260,6 +260,9 @@ class PositionRotaryEmbedding:
         self._seq_len_cached = 0
         self._cos_cached = None
         self._sin_cached = None
+        # tables that were replaced by longer ones: captured decode graphs hold raw pointers into them, and every
+        # position such a graph can see lies inside the table it captured, so they only have to stay allocated
+        self._retired = []
 
     @classmethod
     def static(cls, dim, base, device, scaling_factor=1.0):
@@ -268,6 +271,8 @@ class PositionRotaryEmbedding:
 
     def tables(self, dtype, device, seqlen: int):
         if seqlen > self._seq_len_cached or self._cos_cached.device != device or self._cos_cached.dtype != dtype:
+            if self._cos_cached is not None:
+                self._retired.append((self._cos_cached, self._sin_cached))
             self._seq_len_cached = seqlen
             t = torch.arange(seqlen, device=device, dtype=self.inv_freq.dtype)
             if self.scaling_factor != 1.0:
