@@ -44,6 +44,8 @@ CONFIGS = {
     "llama-tiny-gptq": (dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
                              num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5), "gptq", "float16", 4, 64),
 }
+# cfg1 of BASELINE.json: the padded causal_lm path on CPU (plumbing config; no GPU, no HIP kernels involved)
+CPU_CONFIGS = {"gpt2-cpu": dict(vocab_size=50257, n_embd=768, n_layer=12, n_head=12, n_positions=1024, batch=4, l_in=16)}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 achievable
 
 
@@ -145,17 +147,96 @@ def pmc_traffic(config, B, ctx_mean):
     return int(d["fetch_bytes_per_launch_corrected"] + (d.get("write_bytes_per_launch_uncalibrated") or 0))
 
 
+def bench_causal_lm_cpu(args):
+    """BASELINE config 1: GPT-2 small (124 M, random init, fp32) through CausalLMBatch / CausalLM.generate_token on the
+    hf_transformers engine, CPU, batch 4, prompts of 16 tokens.  A step = one NextToken-equivalent generate_token call.
+    `cpu_baseline` = the oracle's fp32 GPT-2 restatement driven through the same greedy loop."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import GPT2Config, GPT2LMHeadModel, PreTrainedTokenizerFast
+
+    from tgis_amd.inference_engine.hf_transformers import InferenceEngine
+    from tgis_amd.models.causal_lm import CausalLM
+    from tgis_amd.pb import generate_pb2 as pb2
+
+    c = CPU_CONFIGS[args.config]
+    B, L_in = args.batch or c["batch"], c["l_in"]
+    K, W = args.steps, args.warmup
+    os.environ["CUDA_VISIBLE_DEVICES"] = os.environ["HIP_VISIBLE_DEVICES"] = ""  # this config is the CPU path
+    threads = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(threads)
+    torch.manual_seed(1234)
+    hf = GPT2LMHeadModel(GPT2Config(vocab_size=c["vocab_size"], n_embd=c["n_embd"], n_layer=c["n_layer"], n_head=c["n_head"],
+                                    n_positions=c["n_positions"], attn_pdrop=0.0, resid_pdrop=0.0, embd_pdrop=0.0,
+                                    pad_token_id=0, bos_token_id=1, eos_token_id=2))
+    vocab = {"<pad>": 0, "<s>": 1, "</s>": 2, **{f"t{i}": i for i in range(3, c["vocab_size"])}}
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<pad>"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok = PreTrainedTokenizerFast(tokenizer_object=tk, eos_token="</s>", bos_token="<s>", unk_token="<pad>",
+                                  pad_token="<pad>", padding_side="left", truncation_side="left")
+    lm = CausalLM("gpt2-small-random", None, "hf_transformers", torch.float32, None,
+                  engine=InferenceEngine(None, None, torch.float32, None, None, 1024, preloaded=hf, tokenizer=tok))
+    assert lm.device.type == "cpu"
+    g = torch.Generator().manual_seed(1234)
+    prompts = [torch.randint(3, c["vocab_size"], (L_in,), generator=g).tolist() for _ in range(B)]
+    reqs = [pb2.Request(id=i, inputs=" ".join(f"t{t}" for t in p), input_length=L_in, truncate=True,
+                        max_output_length=W + K + 1) for i, p in enumerate(prompts)]
+    with lm.context_manager():
+        batch, errs = lm.batch_type.from_pb(pb2.Batch(id=0, requests=reqs), tok, lm.dtype, lm.device, lm.word_embeddings,
+                                            None, lm.use_position_ids)
+        assert not errs
+        t0 = time.perf_counter()
+        lm.generate_token(batch, first=True)
+        prefill_ms = (time.perf_counter() - t0) * 1e3
+        ids = []
+        for _ in range(W):
+            lm.generate_token(batch)
+        step_ms = []
+        t0 = time.perf_counter()
+        for _ in range(K):
+            ts = time.perf_counter()
+            toks = lm.generate_token(batch)[0]
+            step_ms.append((time.perf_counter() - ts) * 1e3)
+            ids.append([t.token_id for t in toks])
+        elapsed = time.perf_counter() - t0
+    out = {"metric": f"decode tokens/sec (GPT-2 small fp32 CPU causal_lm, batch {B}) + p50 step latency",
+           "value": round(B * K / elapsed, 2), "unit": "tokens/s", "n_gpus": 0, "steps": K, "warmup": W,
+           "ms_per_step": round(elapsed / K * 1e3, 4), "p50_step_ms": round(sorted(step_ms)[len(step_ms) // 2], 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic (seeded random-init GPT-2 small, seeded token ids)",
+           "config": {"workload": f"gpt2-small fp32 CPU causal_lm (padded batch), B={B}, L_in={L_in}, prefill + {W} warm-up + "
+                                  f"{K} timed decode steps, greedy", "global_batch": B, "seq_len": L_in + W + K,
+                      "parallelism": "cpu", "threads": threads, "prefill_ms": round(prefill_ms, 2)},
+           "roofline": None}
+    if not args.no_cpu_baseline:
+        from oracle.gpt2_ref import GPT2Ref
+
+        class _Cfg:
+            n_embd, n_head, n_layer, layer_norm_epsilon, activation_function = c["n_embd"], c["n_head"], c["n_layer"], 1e-5, "gelu_new"
+
+        sd = {k: v for k, v in hf.state_dict().items()}
+        ref = GPT2Ref(_Cfg, sd)
+        n = min(8, K)
+        t0 = time.perf_counter()
+        want = ref.generate_greedy(prompts, n + 1)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(B * (n + 1) / dt, 2), "unit": "tokens/s", "cores": threads, "kind": "port",
+                               "sample": f"oracle/gpt2_ref.py greedy loop, prefill + {n} decode steps, B={B}, fp32"}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="llama2-7b-gptq", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="llama2-7b-gptq", choices=sorted(list(CONFIGS) + list(CPU_CONFIGS)))
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--ctx", type=int, default=None, help="mean context length over the timed steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if args.config in CPU_CONFIGS:
+        return bench_causal_lm_cpu(args)
 
     rank = int(os.getenv("RANK", "0"))
     world = int(os.getenv("WORLD_SIZE", "1"))

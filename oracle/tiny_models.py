@@ -187,3 +187,54 @@ def tiny_bigcode_tensors(cfg, seed: int, dtype=torch.float16, embed_scale: float
         lin(f"{p}.mlp.c_proj", E, I)
     ln("transformer.ln_f")
     return t
+
+
+class TinyGPT2Config:
+    """GPT-2 (multi-head attention, learned positions, LayerNorm, gelu_new, tied head): BASELINE config 1's family."""
+    model_type = "gpt2"
+
+    def __init__(self, vocab_size=256, n_embd=64, n_layer=2, n_head=4, n_positions=128, layer_norm_epsilon=1e-5,
+                 activation_function="gelu_new"):
+        self.vocab_size = vocab_size
+        self.n_embd = self.hidden_size = n_embd
+        self.n_layer = self.num_hidden_layers = n_layer
+        self.n_head = self.num_attention_heads = n_head
+        self.n_inner = 4 * n_embd
+        self.n_positions = n_positions
+        self.layer_norm_epsilon = layer_norm_epsilon
+        self.activation_function = activation_function
+        self.pad_token_id = 0
+        self.bos_token_id = 1
+        self.eos_token_id = 2
+
+    def to_dict(self):
+        return {k: v for k, v in vars(self).items()}
+
+
+def tiny_gpt2_tensors(cfg, seed: int, embed_scale: float = 6.0) -> Dict[str, torch.Tensor]:
+    """fp32 state dict in HF GPT2LMHeadModel naming.  Linear weights are stored [in, out] (HF's Conv1D).  The head is
+    tied to wte, so the embedding table is scaled up to get decisive greedy margins."""
+    g = torch.Generator().manual_seed(seed)
+    E, I, V = cfg.n_embd, cfg.n_inner, cfg.vocab_size
+    t: Dict[str, torch.Tensor] = {}
+
+    def conv1d(name, k, n):
+        t[f"{name}.weight"] = torch.randn(k, n, generator=g) * k ** -0.5
+        t[f"{name}.bias"] = torch.randn(n, generator=g) * 0.1
+
+    def ln(name):
+        t[f"{name}.weight"] = 1.0 + 0.1 * torch.randn(E, generator=g)
+        t[f"{name}.bias"] = 0.1 * torch.randn(E, generator=g)
+
+    t["transformer.wte.weight"] = torch.randn(V, E, generator=g) * embed_scale * E ** -0.5
+    t["transformer.wpe.weight"] = torch.randn(cfg.n_positions, E, generator=g) * 0.3
+    for i in range(cfg.n_layer):
+        p = f"transformer.h.{i}"
+        ln(f"{p}.ln_1")
+        conv1d(f"{p}.attn.c_attn", E, 3 * E)
+        conv1d(f"{p}.attn.c_proj", E, E)
+        ln(f"{p}.ln_2")
+        conv1d(f"{p}.mlp.c_fc", E, I)
+        conv1d(f"{p}.mlp.c_proj", I, E)
+    ln("transformer.ln_f")
+    return t

@@ -1,0 +1,241 @@
+"""BASELINE config 1 (row a19): the padded `CausalLMBatch` / `CausalLM` path on the `hf_transformers` engine, on CPU,
+against fixtures captured from the reference's own `causal_lm` path (tests/golden/make_gpt2_fixtures.py).
+
+Pinned bit-exact: every batch tensor after `from_pb` (input_ids, attention_mask, position_ids, all_input_ids_tensor,
+input_lengths, padding_right_offset, max_sequence_length), after decode steps, after `concatenate` and after `prune`;
+token ids, ranks and request order of every step — including seeded sampling, whose per-request torch.Generator
+streams are reproducible on CPU.  Logits / logprobs: the same library model on the same machine class, fp32 — 2e-4
+absolute (thread-count dependent summation order)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.tiny_models import TinyGPT2Config, tiny_gpt2_tensors
+from tests.fixture_utils import GOLDEN, load_fixture
+
+LOGIT_TOL = 2e-4
+
+
+def _extra(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: z[k] for k in z.files if not k.startswith("s") or not k[1].isdigit()}
+
+
+@pytest.fixture(scope="module")
+def lm():
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import GPT2Config, GPT2LMHeadModel, PreTrainedTokenizerFast
+
+    from tgis_amd.inference_engine.hf_transformers import InferenceEngine
+    from tgis_amd.models.causal_lm import CausalLM
+
+    cfg = TinyGPT2Config()
+    vocab = {"<pad>": 0, "<s>": 1, "</s>": 2, **{f"t{i}": i for i in range(3, cfg.vocab_size)}}
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<pad>"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok = PreTrainedTokenizerFast(tokenizer_object=tk, eos_token="</s>", bos_token="<s>", unk_token="<pad>",
+                                  pad_token="<pad>", padding_side="left", truncation_side="left")
+    hf = GPT2LMHeadModel(GPT2Config(
+        vocab_size=cfg.vocab_size, n_embd=cfg.n_embd, n_layer=cfg.n_layer, n_head=cfg.n_head, n_positions=cfg.n_positions,
+        layer_norm_epsilon=cfg.layer_norm_epsilon, activation_function=cfg.activation_function, attn_pdrop=0.0,
+        resid_pdrop=0.0, embd_pdrop=0.0, pad_token_id=0, bos_token_id=1, eos_token_id=2))
+    sd = {k: v.float() for k, v in tiny_gpt2_tensors(cfg, seed=17).items()}
+    sd["lm_head.weight"] = sd["transformer.wte.weight"]
+    missing, unexpected = hf.load_state_dict(sd, strict=False)
+    assert not unexpected
+    eng = InferenceEngine(None, None, torch.float32, None, None, 128, preloaded=hf, tokenizer=tok)
+    model = CausalLM("gpt2-tiny", None, "hf_transformers", torch.float32, None, engine=eng)
+    assert model.use_position_ids and model.device.type == "cpu"
+    return model
+
+
+def _pb(blob):
+    from tgis_amd.pb import generate_pb2 as pb2
+
+    b = pb2.Batch()
+    b.ParseFromString(bytes(blob))
+    return b
+
+
+def _requests(prompts, max_new, first_id=0, batch_id=0, truncate_to=None):
+    from tests.fixture_utils import prompt_text
+    from tgis_amd.pb import generate_pb2 as pb2
+
+    reqs = []
+    for i, p in enumerate(prompts):
+        keep = len(p) if truncate_to is None or truncate_to[i] is None else truncate_to[i]
+        r = pb2.Request(id=first_id + i, inputs=prompt_text(p), input_length=keep, truncate=keep != len(p),
+                        max_output_length=max_new[i] if isinstance(max_new, list) else max_new)
+        r.details.logprobs = True
+        r.details.top_n_toks = 2
+        r.details.ranks = True
+        reqs.append(r)
+    return pb2.Batch(id=batch_id, requests=reqs)
+
+
+def _from_pb(lm, pb):
+    with lm.context_manager():
+        batch, errs = lm.batch_type.from_pb(pb, lm.tokenizer, lm.dtype, lm.device, lm.word_embeddings, lm.prefix_cache,
+                                            lm.use_position_ids)
+    assert not errs
+    return batch
+
+
+class _Tap:
+    def __init__(self, lm):
+        self.lm, self.last = lm, None
+        orig = lm.forward
+
+        def fwd(*a, **kw):
+            out = orig(*a, **kw)
+            self.last = out[0][:, -1, :].detach().float().numpy().copy()
+            return out
+
+        lm.forward = fwd
+
+    def close(self):
+        del self.lm.forward
+
+
+def _step(lm, tap, batch, first=False, for_concat=False):
+    with lm.context_manager():
+        toks, in_toks, errs, ns = lm.generate_token(batch, first=first, for_concat=for_concat)
+    assert not errs and ns > 0
+    return toks, in_toks, tap.last
+
+
+def _same_state(batch, extra, tag):
+    np.testing.assert_array_equal(batch.input_ids.numpy(), extra[f"{tag}_input_ids"], err_msg=f"{tag}: input_ids")
+    np.testing.assert_array_equal(batch.attention_mask.numpy(), extra[f"{tag}_attention_mask"], err_msg=f"{tag}: mask")
+    np.testing.assert_array_equal(batch.all_input_ids_tensor.numpy(), extra[f"{tag}_all_input_ids"],
+                                  err_msg=f"{tag}: all_input_ids_tensor")
+    np.testing.assert_array_equal(batch.position_ids.numpy(), extra[f"{tag}_position_ids"], err_msg=f"{tag}: positions")
+    assert batch.input_lengths == extra[f"{tag}_input_lengths"].tolist(), f"{tag}: input_lengths"
+    assert batch.max_remaining_tokens == extra[f"{tag}_remaining"].tolist(), f"{tag}: max_remaining_tokens"
+    assert [batch.max_sequence_length, batch.padding_right_offset] == extra[f"{tag}_geometry"].tolist(), f"{tag}: geometry"
+
+
+def _same_tokens(toks, logits, want, what, exact_ids=True):
+    assert [t.request_id for t in toks] == want["request_ids"].tolist(), f"{what}: request order"
+    assert [t.token_id for t in toks] == want["ids"].tolist(), f"{what}: token ids"
+    assert [t.rank for t in toks] == want["ranks"].tolist(), f"{what}: ranks"
+    np.testing.assert_allclose(logits, want["logits"], atol=LOGIT_TOL, rtol=0, err_msg=f"{what}: logits")
+    np.testing.assert_allclose([t.logprob for t in toks], want["logprobs"], atol=LOGIT_TOL, rtol=0,
+                               err_msg=f"{what}: logprobs")
+    for t, wt in zip(toks, want["top"]):
+        assert [tt.token_id for tt in t.top_tokens] == [x[0] for x in wt], f"{what}: top-n ids"
+
+
+def test_equal_length_batch_32_new_tokens(lm):
+    """B = 4 prompts of 16 tokens, 32 new tokens: the workload of BASELINE config 1."""
+    meta, steps = load_fixture("gpt2_equal")
+    extra = _extra("gpt2_equal")
+    assert meta["batch_type"] == "CausalLMBatch" and meta["use_position_ids"]
+    batch = _from_pb(lm, _pb(extra["pb"]))
+    _same_state(batch, extra, "frompb")
+    tap = _Tap(lm)
+    try:
+        for i, want in enumerate(steps):
+            toks, in_toks, logits = _step(lm, tap, batch, first=(i == 0))
+            _same_tokens(toks, logits, want, f"equal step {i}")
+            if i == 0:  # input-token details were requested: one entry per prompt token, the first without a logprob
+                assert len(in_toks) == 4 and all(len(it.tokens) == 16 for it in in_toks)
+            if f"after{i}_input_ids" in extra:
+                _same_state(batch, extra, f"after{i}")
+    finally:
+        tap.close()
+    assert batch.padding_right_offset == 0 and batch.max_sequence_length == 48
+
+
+def test_padded_batch_with_truncation(lm):
+    meta, steps = load_fixture("gpt2_padded")
+    extra = _extra("gpt2_padded")
+    batch = _from_pb(lm, _requests(meta["prompts"], meta["max_new"], truncate_to=meta["truncate_to"]))
+    _same_state(batch, extra, "frompb")
+    assert batch.input_lengths == [5, 20, 17, 1] and batch.max_sequence_length == 20
+    tap = _Tap(lm)
+    try:
+        for i, want in enumerate(steps):
+            toks, _, logits = _step(lm, tap, batch, first=(i == 0))
+            _same_tokens(toks, logits, want, f"padded step {i}")
+            _same_state(batch, extra, f"after{i}")
+    finally:
+        tap.close()
+
+
+def test_continuous_batching_concatenate_prune(lm):
+    meta, steps = load_fixture("gpt2_continuous")
+    extra = _extra("gpt2_continuous")
+    tap = _Tap(lm)
+    try:
+        a = _from_pb(lm, _requests(meta["prompts_a"], meta["max_new_a"], first_id=0, batch_id=1))
+        got = [_step(lm, tap, a, first=True), _step(lm, tap, a), _step(lm, tap, a)]
+        b = _from_pb(lm, _requests(meta["prompts_b"], meta["max_new_b"], first_id=2, batch_id=2))
+        got.append(_step(lm, tap, b, first=True, for_concat=True))
+        _same_state(a, extra, "a_before_concat")
+        _same_state(b, extra, "b_before_concat")
+        with lm.context_manager():
+            merged = lm.batch_type.concatenate([a, b])
+        _same_state(merged, extra, "merged")
+        assert merged.batch_id == 1 and len(merged) == 3
+        kv = merged.past_key_values[0][0]
+        assert kv.shape[0] == 3 and kv.shape[2] == merged.max_sequence_length - 1
+        got += [_step(lm, tap, merged), _step(lm, tap, merged)]
+        with lm.context_manager():
+            merged = lm.batch_type.prune(merged, [2])
+        _same_state(merged, extra, "pruned")
+        got += [_step(lm, tap, merged), _step(lm, tap, merged)]
+        _same_state(merged, extra, "final")
+    finally:
+        tap.close()
+    for i, ((toks, _, logits), want) in enumerate(zip(got, steps)):
+        _same_tokens(toks, logits, want, f"continuous step {i}")
+    with lm.context_manager():
+        assert lm.batch_type.prune(merged, [0, 1]) is None
+        with pytest.raises(ValueError):
+            lm.batch_type.concatenate([_from_pb(lm, _requests(meta["prompts_b"], 3)), merged])
+
+
+def test_seeded_sampling_and_processors_reproduce_the_reference_on_cpu(lm):
+    meta, steps = load_fixture("gpt2_sampled")
+    batch = _from_pb(lm, _pb(_extra("gpt2_sampled")["pb"]))
+    tap = _Tap(lm)
+    try:
+        for i, want in enumerate(steps):
+            toks, _, logits = _step(lm, tap, batch, first=(i == 0))
+            assert [t.token_id for t in toks] == want["ids"].tolist(), f"sampled step {i}: token ids"
+            np.testing.assert_allclose(logits, want["logits"], atol=LOGIT_TOL, rtol=0)
+            np.testing.assert_allclose([t.logprob for t in toks], want["logprobs"], atol=1e-3, rtol=0)
+    finally:
+        tap.close()
+
+
+def test_get_model_dispatch_honours_the_deployment_framework(tmp_path, lm, monkeypatch):
+    """A checkpoint directory + `hf_transformers` -> CausalLM on that engine plugin (CPU here); asking for the flash
+    path without a GPU fails loudly instead of falling back."""
+    from tgis_amd.models import get_model
+    from tgis_amd.models.causal_lm import CausalLM
+
+    lm.model.save_pretrained(tmp_path, safe_serialization=True)
+    lm.tokenizer.save_pretrained(tmp_path)
+    monkeypatch.delenv("FLASH_ATTENTION", raising=False)
+    m = get_model(str(tmp_path), None, "hf_transformers", "float32", None, 128)
+    assert isinstance(m, CausalLM) and type(m.engine).__module__.endswith("inference_engine.hf_transformers")
+    assert m.dtype == torch.float32 and m.batch_type.__name__ == "CausalLMBatch"
+    meta, steps = load_fixture("gpt2_equal")
+    batch = _from_pb(m, _pb(_extra("gpt2_equal")["pb"]))
+    with m.context_manager():
+        toks, _, errs, _ = m.generate_token(batch, first=True)
+    assert [t.token_id for t in toks] == steps[0]["ids"].tolist()
+    with pytest.raises(ValueError, match="Quantization requires CUDA"):
+        get_model(str(tmp_path), None, "hf_transformers", "float32", "gptq", 128)
+    if not torch.cuda.is_available():
+        monkeypatch.setenv("FLASH_ATTENTION", "true")
+        with pytest.raises(NotImplementedError):
+            get_model(str(tmp_path), None, "tgis_native", "float16", None, 128)
+        monkeypatch.delenv("FLASH_ATTENTION")
+        with pytest.raises(ModuleNotFoundError):
+            get_model(str(tmp_path), None, "no_such_engine", "float32", None, 128)

@@ -109,3 +109,25 @@ def test_santacoder_oracle_matches_reference_generate(scenario):
         np.testing.assert_allclose(g["logits"].numpy(), w["logits"], atol=LOGIT_ATOL, rtol=1e-4, err_msg=f"step {i}")
         assert g["token_ids"].tolist() == w["ids"].tolist(), f"step {i}"
         np.testing.assert_allclose(g["logprobs"].numpy(), w["logprobs"], atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["gpt2_equal", "gpt2_padded"])
+def test_gpt2_oracle_reproduces_reference_fixture(name):
+    """oracle/gpt2_ref.py (BASELINE config 1's family) against the reference's padded causal_lm path: the var-len
+    restatement must give the logits the left-padded batch gave (a truncated request contributes its last
+    `truncate_to` tokens)."""
+    from oracle.gpt2_ref import GPT2Ref
+    from oracle.tiny_models import TinyGPT2Config, tiny_gpt2_tensors
+
+    meta, steps = load_fixture(name)
+    cfg = TinyGPT2Config()
+    ref = GPT2Ref(cfg, tiny_gpt2_tensors(cfg, seed=meta["seed"], embed_scale=meta["embed_scale"]))
+    prompts = meta["prompts"]
+    if meta.get("truncate_to"):
+        prompts = [p if k is None else p[-k:] for p, k in zip(prompts, meta["truncate_to"])]
+    n = min(len(steps), 8)
+    want = ref.generate_greedy(prompts, n, forced=[s["ids"].tolist() for s in steps[:n]])
+    for i in range(n):
+        np.testing.assert_allclose(want[i]["logits"].numpy(), steps[i]["logits"], atol=2e-3, rtol=0)
+        assert want[i]["token_ids"].tolist() == steps[i]["ids"].tolist()
+        np.testing.assert_allclose(want[i]["logprobs"].numpy(), steps[i]["logprobs"], atol=2e-3, rtol=0)
