@@ -58,7 +58,8 @@ int tgis_device_info(int device, int* num_cus, int64_t* hbm_bytes, char* name, i
 #define TGIS_OP_ROPE_KV 4
 #define TGIS_OP_ACT 5
 #define TGIS_OP_SAMPLE 6
-#define TGIS_OP_COUNT 7
+#define TGIS_OP_DECODE_TAIL 7
+#define TGIS_OP_COUNT 8
 int tgis_timing_enable(int on);
 int tgis_timing_reset(void);
 int tgis_timing_read(int op, int64_t* count, double* total_ms);
@@ -241,6 +242,62 @@ int tgis_warp_sample(const float* logits, int64_t ld_logits, float* scores, int6
                      int64_t ld_ids, int64_t L, int64_t exclude_id, const float* eos_adjust, int64_t eos_id,
                      const int* do_sample, uint64_t* rng, int64_t* next_ids, float* next_logprob, float* lse,
                      void* stream);
+
+/* ---- persistent decode tail of a Llama layer --------------------------------------------------------------------
+ * Everything the decode step runs between two attention launches, in ONE launch (fp16, int4 GPTQ linears, M <= 32
+ * rows, one shard):  o_proj -> add + RMSNorm -> gate_up (SiLU * up) -> down -> add + RMSNorm [-> qkv of the NEXT
+ * layer -> rotary + KV-cache write of the next layer].  Replaces, with bit-identical results, the call sequence
+ * tgis_gptq_gemm_f16_partial / tgis_rmsnorm_residual_partial / tgis_gptq_gemm_f16(act=2) /
+ * tgis_gptq_gemm_f16_partial / tgis_rmsnorm_residual_partial / tgis_gptq_gemm_f16_partial /
+ * tgis_rope_kv_write_partial, i.e. the reference's FlashLlamaLayer tail + the next layer's head
+ * (custom_modeling/flash_llama_modeling.py:285-297,383-385,332-335,368,251-282).  One workgroup per CU stays resident
+ * for the whole launch; the phases are separated by grid barriers (8 group counters -> top counter -> 8 generation
+ * words, relaxed agent-scope polling, every spin bounded) and hand their results over as sc1 write-through stores /
+ * sc1 loads.  All buffers are caller-owned; slab buffers hold tgis_llama_decode_tail_slab_bytes(M, K, N) bytes.
+ * `qkv.prepared == NULL` ends the launch after the second norm (last layer: norm2_weight is then the final norm).
+ * The GPU must not be shared with another process's persistent launch (tensor-parallel ranks on one device). */
+typedef struct tgis_tail_linear {
+    const void* prepared; /* image made by tgis_gptq_prepare (gate_up: with flags bit 0) */
+    const void* bias;     /* f16 [N] or NULL */
+    int64_t K, N, groups;
+} tgis_tail_linear;
+
+typedef struct tgis_tail_args {
+    int64_t M, hidden;
+    float eps;
+    const void* attn_out;    /* f16 [M, o_proj.K]: the attention output */
+    const void* residual_in; /* f16 [M, hidden]: the residual stream before attention */
+    tgis_tail_linear o_proj, gate_up, down, qkv;
+    const void* norm1_weight; /* post-attention norm */
+    const void* norm2_weight; /* next layer's input norm, or the final norm */
+    void* y1;   /* f16 [M, hidden] scratch: normed input of gate_up */
+    void* res1; /* f16 [M, hidden] scratch: residual after attention */
+    void* act;  /* f16 [M, down.K] scratch: SiLU(gate) * up */
+    void* y2;   /* f16 [M, hidden] out: normed hidden state (input of the next qkv / of the head) */
+    void* res2; /* f16 [M, hidden] out: residual stream after the layer */
+    float* slabs_o;
+    float* slabs_down;
+    float* slabs_qkv; /* NULL without qkv */
+    void* qkv_out;    /* f16 [M, (H + 2 Hkv) D] out: rotated q, k, v of the next layer */
+    const void* cos;  /* f16 [max_pos, rot_dim / 2] or NULL (no rotation) */
+    const void* sin;
+    const int32_t* positions; /* [M] */
+    const int32_t* slots;     /* [M] physical cache slots of the new tokens */
+    void* k_pool;             /* next layer's pools (see tgis_rope_kv_write) */
+    void* v_pool;
+    int H, Hkv, D, rot_dim;
+} tgis_tail_args;
+
+int64_t tgis_llama_decode_tail_slab_bytes(int64_t M, int64_t K, int64_t N);
+/* 1 if the tail can run a layer of these shapes: only M, hidden and K / N / groups of the four linears are read
+ * (qkv.K == 0 asks about a last layer).  The kernel exists for the plan signatures listed in csrc/decode_tail.hip. */
+int tgis_llama_decode_tail_fits(const tgis_tail_args* shapes);
+int tgis_llama_decode_tail(const tgis_tail_args* args, void* stream);
+/* Debug aid: enable > 0 makes later launches record, per workgroup, 16 s_memrealtime stamps (100 MHz) at the edges of
+ * the phases; `out` (may be NULL) receives [max_workgroups][16] stamps of the last launch; enable == 0 stops. */
+int tgis_llama_decode_tail_trace(int enable, long long* out, int max_workgroups);
+/* 1 if a grid barrier of this device ever hit its spin limit (its results are then invalid); `reset` re-arms. */
+int tgis_llama_decode_tail_status(int reset);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,7 @@ Mirrors custom_modeling/flash_llama_modeling.py of the reference — `LlamaConfi
   * logits are produced in fp32.
 Tensor-parallel sharding follows the reference exactly (heads split across ranks, qkv / gate_up
 column-parallel, o_proj / down_proj row-parallel + all-reduce, vocab-parallel embedding and head)."""
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -73,6 +74,13 @@ class KVArgs:
     fresh_prefill: bool = False        # every sequence starts at cache position 0: page-wise cache writes
 
 
+# TGIS_DECODE_TAIL=true: decode batches of up to 32 rows run everything between two attention launches as ONE
+# persistent launch (csrc/decode_tail.hip, bit-identical results).  Off by default: measured on cfg3 the launch takes
+# 67 us against 64 us for the seven launches it replaces (profiles/r02_decode_tail.md) — the six grid barriers cost
+# what the saved dispatch ramps and the cross-barrier weight prefetch gain.
+DECODE_TAIL = os.getenv("TGIS_DECODE_TAIL", "false").lower() in ("1", "true")
+
+
 class LlamaRMSNorm:
     def __init__(self, prefix, weights, eps=1e-6):
         self.weight = weights.get_tensor(f"{prefix}.weight").contiguous()
@@ -124,17 +132,21 @@ class FlashLlamaAttention:
         self.o_proj = TensorParallelRowLinear.load(config, prefix=f"{prefix}.o_proj", weights=weights,
                                                    bias=config.attention_bias)
 
-    def forward(self, hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id: int, kv: KVArgs):
+    def project_qkv(self, hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id: int, kv: KVArgs):
+        """qkv GEMM, rotation of q and k in place, k and v scattered to their page slots (reference :251-268,282)."""
         H, Hkv, D = self.num_heads, self.num_key_value_heads, self.head_size
         # [T, (H + 2 Hkv) D]; at decode sizes the split-K sum of the GPTQ GEMM is finished inside the rope kernel
         qkv = self.query_key_value(hidden_states, partial=True)
         k_pool, v_pool = kv.cache.k_pool(layer_id), kv.cache.v_pool(layer_id)
-        # rotate q,k in place and scatter k,v to their page slots (reference :252-268,282)
         if kv.fresh_prefill and not isinstance(qkv, native.Partial):
-            qkv = native.rope_kv_write_prefill(qkv, cos, sin, position_ids, cu_seqlens_q, kv.block_tables, k_pool, v_pool,
-                                               kv.max_q_len, H, Hkv, D, D)
-        else:
-            qkv = native.rope_kv_write(qkv, cos, sin, position_ids, kv.slots, k_pool, v_pool, H, Hkv, D, D)
+            return native.rope_kv_write_prefill(qkv, cos, sin, position_ids, cu_seqlens_q, kv.block_tables, k_pool, v_pool,
+                                                kv.max_q_len, H, Hkv, D, D)
+        return native.rope_kv_write(qkv, cos, sin, position_ids, kv.slots, k_pool, v_pool, H, Hkv, D, D)
+
+    def attend(self, qkv, cu_seqlens_q, layer_id: int, kv: KVArgs):
+        """Attention of the rotated q over the layer's cache pages (reference :271-295): [T, H D]."""
+        H, Hkv, D = self.num_heads, self.num_key_value_heads, self.head_size
+        k_pool, v_pool = kv.cache.k_pool(layer_id), kv.cache.v_pool(layer_id)
         T = qkv.shape[0]
         attn_output = torch.empty((T, H * D), dtype=qkv.dtype, device=qkv.device)
         B = kv.block_tables.shape[0]
@@ -145,6 +157,11 @@ class FlashLlamaAttention:
             ws.ensure(native.attn_workspace_bytes(T, H, D, kv.num_splits))
         native.attn_paged(qkv, qkv.stride(0), k_pool, v_pool, kv.block_tables, kv.ctx_lens, cu_seqlens_q,
                           attn_output, B, H, Hkv, D, kv.max_q_len, kv.max_ctx, self.softmax_scale, kv.num_splits, ws)
+        return attn_output
+
+    def forward(self, hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id: int, kv: KVArgs):
+        qkv = self.project_qkv(hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id, kv)
+        attn_output = self.attend(qkv, cu_seqlens_q, layer_id, kv)
         # may be a native.Partial: the following fused add+RMSNorm finishes the split-K sum
         return self.o_proj(attn_output, partial=True)
 
@@ -211,6 +228,56 @@ class FlashLlamaModel:
         self.num_heads = self.layers[0].self_attn.num_heads
         self.num_key_value_heads = config.num_key_value_heads // process_group.size()
         self.max_positions = 0
+        self._tails = None  # per layer native.DecodeTail, built at the first decode step that can use them
+
+    # ---- persistent decode tail (csrc/decode_tail.hip) --------------------------------------------------------------
+    def _decode_tails(self, rows: int):
+        """One native.DecodeTail per layer, or False when this model / batch cannot use them (tensor parallel shards
+        have an all-reduce between the phases; dense, act-order or wide-plan linears keep the separate launches)."""
+        if self._tails is None:
+            self._tails = self._build_decode_tails() if DECODE_TAIL and self.tp_world_size == 1 else False
+        if self._tails is False or rows > 32:
+            return False
+        return self._tails
+
+    def _build_decode_tails(self):
+        def gptq(lin):
+            h = getattr(lin, "q_handle", None)
+            return None if h is None or h.perm is not None else (h, lin.bias)
+
+        tails = []
+        for i, layer in enumerate(self.layers):
+            nxt = self.layers[i + 1] if i + 1 < len(self.layers) else None
+            o, gu, down = (gptq(layer.self_attn.o_proj.linear), gptq(layer.mlp.gate_up_proj.linear),
+                           gptq(layer.mlp.down_proj.linear))
+            qkv = gptq(nxt.self_attn.query_key_value.linear) if nxt is not None else None
+            if None in (o, gu, down) or not layer.mlp.fused_epilogue or (nxt is not None and qkv is None):
+                return False
+            if layer.input_layernorm.weight.dtype != torch.float16:
+                return False
+            if not native.decode_tail_fits(32, o[0], gu[0], down[0], qkv[0] if qkv is not None else None):
+                return False
+            att = layer.self_attn
+            tails.append(native.DecodeTail(
+                o, gu, down, layer.post_attention_layernorm.weight,
+                nxt.input_layernorm.weight if nxt is not None else self.norm.weight,
+                layer.post_attention_layernorm.variance_epsilon, qkv=qkv, H=att.num_heads,
+                Hkv=att.num_key_value_heads, D=att.head_size, rot_dim=att.head_size))
+        return tails
+
+    def _forward_decode_tail(self, tails, hidden_states, cos, sin, position_ids, cu_seqlens_q, kv: KVArgs):
+        """embedding -> [norm, qkv, rope] of layer 0 -> per layer: attention launch + one persistent tail launch that
+        ends with the next layer's rotated qkv and cache write (the last one ends with the final norm)."""
+        first = self.layers[0]
+        normed, residual = first.input_layernorm(hidden_states, None)
+        qkv = first.self_attn.project_qkv(normed, cos, sin, position_ids, cu_seqlens_q, 0, kv)
+        for i, (layer, tail) in enumerate(zip(self.layers, tails)):
+            attn_output = layer.self_attn.attend(qkv, cu_seqlens_q, layer.layer_id, kv)
+            last = i + 1 == len(self.layers)
+            hidden_states, residual, qkv = tail.run(
+                attn_output, residual, cos, sin, position_ids, kv.slots,
+                None if last else kv.cache.k_pool(i + 1), None if last else kv.cache.v_pool(i + 1))
+        return hidden_states  # already through the final norm
 
     def rope_tables(self, dtype, device, max_s: int):
         # Sized once for the model's whole position range, so the tables normally never move.  A longer request
@@ -226,6 +293,10 @@ class FlashLlamaModel:
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
         hidden_states = inputs_embeds if inputs_embeds is not None else self.embed_tokens(input_ids)
         cos, sin = self.rope_tables(hidden_states.dtype, hidden_states.device, max_s)
+        if kv.max_q_len == 1 and not kv.fresh_prefill and hidden_states.dtype == torch.float16:
+            tails = self._decode_tails(hidden_states.shape[0])
+            if tails:
+                return self._forward_decode_tail(tails, hidden_states, cos, sin, position_ids, cu_seqlens_q, kv)
         residual = None
         for layer in self.layers:
             hidden_states, residual = layer(hidden_states, residual, cos, sin, position_ids, cu_seqlens_q, kv)

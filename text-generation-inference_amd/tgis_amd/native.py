@@ -18,12 +18,29 @@ LIB_PATH = os.getenv("TGIS_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "li
 F16, BF16 = 0, 1
 KV_PAGE_TOKENS = 32
 
-OP_GPTQ_GEMM, OP_ATTN, OP_DENSE_GEMM, OP_NORM, OP_ROPE_KV, OP_ACT, OP_SAMPLE = range(7)
+OP_GPTQ_GEMM, OP_ATTN, OP_DENSE_GEMM, OP_NORM, OP_ROPE_KV, OP_ACT, OP_SAMPLE, OP_DECODE_TAIL = range(8)
 
 _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int
 _c_f = ctypes.c_float
 _vp = ctypes.c_void_p
+
+
+
+class TailLinear(ctypes.Structure):
+    """tgis_tail_linear of include/tgis_hip.h."""
+    _fields_ = [("prepared", _vp), ("bias", _vp), ("K", _c_i64), ("N", _c_i64), ("groups", _c_i64)]
+
+
+class TailArgs(ctypes.Structure):
+    """tgis_tail_args of include/tgis_hip.h (same field order)."""
+    _fields_ = [("M", _c_i64), ("hidden", _c_i64), ("eps", _c_f), ("attn_out", _vp), ("residual_in", _vp),
+                ("o_proj", TailLinear), ("gate_up", TailLinear), ("down", TailLinear), ("qkv", TailLinear),
+                ("norm1_weight", _vp), ("norm2_weight", _vp), ("y1", _vp), ("res1", _vp), ("act", _vp), ("y2", _vp),
+                ("res2", _vp), ("slabs_o", _vp), ("slabs_down", _vp), ("slabs_qkv", _vp), ("qkv_out", _vp),
+                ("cos", _vp), ("sin", _vp), ("positions", _vp), ("slots", _vp), ("k_pool", _vp), ("v_pool", _vp),
+                ("H", _c_int), ("Hkv", _c_int), ("D", _c_int), ("rot_dim", _c_int)]
+
 
 # name -> (restype, argtypes); must list every symbol declared in include/tgis_hip.h
 SIGNATURES = {
@@ -73,6 +90,11 @@ SIGNATURES = {
     "tgis_embedding": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _vp]),
     "tgis_decode_slots": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp]),
     "tgis_argmax_logprob": (_c_int, [_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _vp, _vp, _vp]),
+    "tgis_llama_decode_tail_slab_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
+    "tgis_llama_decode_tail_fits": (_c_int, [ctypes.POINTER(TailArgs)]),
+    "tgis_llama_decode_tail": (_c_int, [ctypes.POINTER(TailArgs), _vp]),
+    "tgis_llama_decode_tail_status": (_c_int, [_c_int]),
+    "tgis_llama_decode_tail_trace": (_c_int, [_c_int, _vp, _c_int]),
     "tgis_warp_sample": (_c_int, [_vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64,
                                   _c_i64, _c_i64, _vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
@@ -467,6 +489,79 @@ def attn_paged(q, ld_q: int, k_pool, v_pool, block_tables, ctx_lens, cu_seqlens_
                                        Hkv, D, max_q_len, max_ctx, float(scale), dtype_code(q.dtype), num_splits,
                                        wptr, wbytes, _stream()), "tgis_attn_paged")
     return out
+
+
+# ---- persistent decode tail ---------------------------------------------------------------------------------------
+def _tail_linear(w: "GptqWeight", bias) -> TailLinear:
+    return TailLinear(w.image.data_ptr(), _ptr(bias), w.K, w.N, w.groups)
+
+
+class DecodeTail:
+    """Static part of one layer's tgis_llama_decode_tail call (weights of o_proj / gate_up / down, the post-attention
+    norm, and the next layer's input norm + qkv — or the final norm when there is no next layer)."""
+
+    def __init__(self, o_proj, gate_up, down, norm1_weight, norm2_weight, eps: float, qkv=None, H=0, Hkv=0, D=0,
+                 rot_dim=0):
+        # each linear is (GptqWeight, bias or None); gate_up must have been prepared with gate_up=True
+        assert gate_up[0].flags & 1, "the decode tail needs the fused SiLU*up gate_up image"
+        self.keep = (o_proj, gate_up, down, qkv, norm1_weight, norm2_weight)  # the struct only holds raw pointers
+        self.o_proj, self.gate_up, self.down, self.qkv = o_proj, gate_up, down, qkv
+        self.norm1_weight, self.norm2_weight, self.eps = norm1_weight, norm2_weight, float(eps)
+        self.hidden = o_proj[0].N
+        self.H, self.Hkv, self.D, self.rot_dim = H, Hkv, D, rot_dim
+        self._slab_elems = {}
+
+    def slab_elems(self, M: int):
+        got = self._slab_elems.get(M)
+        if got is None:
+            lib = load_library()
+            got = tuple(lib.tgis_llama_decode_tail_slab_bytes(M, w.K, w.N) // 4 if w is not None else 0
+                        for w in (self.o_proj[0], self.down[0], self.qkv[0] if self.qkv else None))
+            self._slab_elems[M] = got
+        return got
+
+    def run(self, attn_out: torch.Tensor, residual: torch.Tensor, cos=None, sin=None, positions=None, slots=None,
+            k_pool=None, v_pool=None):
+        """Returns (y2, res2, qkv_out or None)."""
+        assert attn_out.dtype == torch.float16 and attn_out.is_contiguous() and residual.is_contiguous()
+        M, dev = attn_out.shape[0], attn_out.device
+        E, I = self.hidden, self.down[0].K
+        h = lambda n: torch.empty((M, n), dtype=torch.float16, device=dev)  # noqa: E731
+        y1, res1, act, y2, res2 = h(E), h(E), h(I), h(E), h(E)
+        so, sd, sq = self.slab_elems(M)
+        f = lambda n: torch.empty(n, dtype=torch.float32, device=dev)  # noqa: E731
+        slabs_o, slabs_d = f(so), f(sd)
+        a = TailArgs()
+        a.M, a.hidden, a.eps = M, E, self.eps
+        a.attn_out, a.residual_in = _ptr(attn_out), _ptr(residual)
+        a.o_proj, a.gate_up, a.down = _tail_linear(*self.o_proj), _tail_linear(*self.gate_up), _tail_linear(*self.down)
+        a.norm1_weight, a.norm2_weight = _ptr(self.norm1_weight), _ptr(self.norm2_weight)
+        a.y1, a.res1, a.act, a.y2, a.res2 = _ptr(y1), _ptr(res1), _ptr(act), _ptr(y2), _ptr(res2)
+        a.slabs_o, a.slabs_down = _ptr(slabs_o), _ptr(slabs_d)
+        qkv_out = slabs_q = None
+        if self.qkv is not None:
+            a.qkv = _tail_linear(*self.qkv)
+            qkv_out, slabs_q = h(self.qkv[0].N), f(sq)
+            a.slabs_qkv, a.qkv_out = _ptr(slabs_q), _ptr(qkv_out)
+            a.cos, a.sin, a.positions, a.slots = _ptr(cos), _ptr(sin), _ptr(positions), _ptr(slots)
+            a.k_pool, a.v_pool = _ptr(k_pool), _ptr(v_pool)
+            a.H, a.Hkv, a.D, a.rot_dim = self.H, self.Hkv, self.D, self.rot_dim
+        _check(load_library().tgis_llama_decode_tail(ctypes.byref(a), _stream()), "tgis_llama_decode_tail")
+        return y2, res2, qkv_out
+
+
+def decode_tail_fits(M: int, o_proj: "GptqWeight", gate_up: "GptqWeight", down: "GptqWeight", qkv=None) -> bool:
+    """Can tgis_llama_decode_tail run a layer with these linears (shapes and plans only)?"""
+    a = TailArgs()
+    a.M, a.hidden = M, o_proj.N
+    for name, w in (("o_proj", o_proj), ("gate_up", gate_up), ("down", down), ("qkv", qkv)):
+        if w is not None:
+            setattr(a, name, TailLinear(None, None, w.K, w.N, w.groups))
+    return bool(load_library().tgis_llama_decode_tail_fits(ctypes.byref(a)))
+
+
+def decode_tail_status(reset: bool = False) -> int:
+    return load_library().tgis_llama_decode_tail_status(int(reset))
 
 
 # ---- elementwise / sampling ---------------------------------------------------------------------------------
