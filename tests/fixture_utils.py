@@ -6,9 +6,11 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-# rows whose reference top-2 logit margin is below this are only required to pick one of the top two ids:
-# fp16 kernels cannot be asked to break a near-tie the way an fp32 run happened to
-TIE_MARGIN = 0.75
+# The fixtures are drawn until the reference decides every token by >= 0.8 logits (Llama) / 0.2 (GPT-BigCode): more
+# than twice the fp16 logit tolerance of the GPU tests, so fp16 runs must reproduce every id exactly.  bf16 runs
+# (tolerance 2.5 / 0.6) cannot be held to that: there a row may take another id only if the reference itself prefers its
+# own by less than 2 x the tolerance, and the tests report how often that happened (TIE_USES).
+TIE_USES = {}
 
 
 def load_fixture(name):
@@ -50,13 +52,18 @@ def prompt_text(ids):
     return " ".join(f"t{i}" for i in ids)
 
 
-def check_ids(got_ids, step, what):
-    """Token ids must equal the reference's; rows the reference itself decided by < TIE_MARGIN may take its runner-up."""
+def check_ids(got_ids, step, what, tie_margin=None):
+    """Token ids must equal the reference's.  tie_margin (bf16 runs only): a row may differ if the reference prefers its
+    own id over the one produced by less than tie_margin; returns how many rows used that, and records it."""
     lg = step["logits"]
-    order = np.argsort(-lg, axis=1)
-    margin = lg[np.arange(len(lg)), order[:, 0]] - lg[np.arange(len(lg)), order[:, 1]]
+    used = 0
     for r, (g, w) in enumerate(zip(got_ids, step["ids"])):
         if int(g) == int(w):
             continue
-        assert margin[r] < TIE_MARGIN and int(g) == int(order[r, 1]), \
-            f"{what}: row {r} token {int(g)} != reference {int(w)} (reference margin {margin[r]:.3f})"
+        gap = float(lg[r, int(w)] - lg[r, int(g)])
+        assert tie_margin is not None and gap < tie_margin, \
+            f"{what}: row {r} token {int(g)} != reference {int(w)} (the reference prefers its own by {gap:.3f})"
+        used += 1
+    if used:
+        TIE_USES[what] = used
+    return used

@@ -99,6 +99,10 @@ def install_shims(tmp):
 
 
 CAPTURE = []
+# every token of a fixture is decided by at least this many logits: > 2x the absolute logit tolerance of the fp16 GPU
+# tests (0.35 for the Llama fixtures with |logit| up to ~60, 0.08 for the GPT-BigCode ones with |logit| up to ~12)
+LLAMA_MARGIN = 0.8
+BIGCODE_MARGIN = 0.2
 
 
 def write_model_dir(path, cfg, tensors, groupsize):
@@ -187,6 +191,30 @@ def step(model, batch, first=False, for_concat=False):
             "logits": CAPTURE[-1].numpy().copy()}
 
 
+def min_margin(steps):
+    """Smallest top-1 minus top-2 logit over every row of every step."""
+    m = float("inf")
+    for st in steps:
+        top2 = np.sort(st["logits"], axis=1)[:, -2:]
+        m = min(m, float((top2[:, 1] - top2[:, 0]).min()))
+    return m
+
+
+def decisive(make, what, need, tries=400):
+    """Draw prompts until the reference decides every token of the scenario by at least `need` logits (SURVEY.md §8c
+    "fixture design note": margins far above the fp16 tolerance of the GPU tests, so that token ids can be compared
+    exactly, without a near-tie rule).  `make()` draws fresh prompts from the shared generator and returns
+    (meta_extra, steps)."""
+    for attempt in range(tries):
+        extra, steps = make()
+        m = min_margin(steps)
+        if m >= need:
+            print(f"{what}: min top-2 margin {m:.3f} after {attempt + 1} draw(s)")
+            extra["min_margin"] = m
+            return extra, steps
+    raise RuntimeError(f"{what}: no draw reached a margin of {need}")
+
+
 def save(name, meta, steps, extra=None):
     arrays = {"meta": np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)}
     for i, s in enumerate(steps):
@@ -222,34 +250,43 @@ def main():
                      "torch": torch.__version__}
 
         # --- scenario 1: equal-length prompts, greedy, logprobs + top-3 + ranks ------------------------------
-        prompts = [rng.integers(3, cfg.vocab_size, size=12).tolist() for _ in range(3)]
-        batch = run_reference(model, make_requests(pb2, prompts, max_new=8, top_n=3, ranks=True))
-        steps = [step(model, batch, first=True)] + [step(model, batch) for _ in range(7)]
-        save(f"llama_{variant}_equal", {**meta_base, "prompts": prompts, "max_new": 8, "top_n": 3, "ranks": True},
-             steps)
+        def equal():
+            prompts = [rng.integers(3, cfg.vocab_size, size=12).tolist() for _ in range(3)]
+            batch = run_reference(model, make_requests(pb2, prompts, max_new=8, top_n=3, ranks=True))
+            return {"prompts": prompts}, [step(model, batch, first=True)] + [step(model, batch) for _ in range(7)]
+
+        extra, steps = decisive(equal, f"llama_{variant}_equal", LLAMA_MARGIN)
+        save(f"llama_{variant}_equal", {**meta_base, **extra, "max_new": 8, "top_n": 3, "ranks": True}, steps)
 
         # --- scenario 2: ragged prompts (the reference left-pads; version-sensitive) -------
-        prompts = [rng.integers(3, cfg.vocab_size, size=n).tolist() for n in (5, 33, 17, 1)]
-        batch = run_reference(model, make_requests(pb2, prompts, max_new=6))
-        steps = [step(model, batch, first=True)] + [step(model, batch) for _ in range(5)]
-        save(f"llama_{variant}_ragged", {**meta_base, "prompts": prompts, "max_new": 6}, steps)
+        def ragged():
+            prompts = [rng.integers(3, cfg.vocab_size, size=n).tolist() for n in (5, 33, 17, 1)]
+            batch = run_reference(model, make_requests(pb2, prompts, max_new=6))
+            return {"prompts": prompts}, [step(model, batch, first=True)] + [step(model, batch) for _ in range(5)]
+
+        extra, steps = decisive(ragged, f"llama_{variant}_ragged", LLAMA_MARGIN)
+        save(f"llama_{variant}_ragged", {**meta_base, **extra, "max_new": 6}, steps)
 
         # --- scenario 3: continuous batching — prefill A, decode, prefill B (for_concat), concatenate, decode,
         #     prune one request of A, decode (server.py:105-231 drives exactly this sequence) ----------------------
-        pa = [rng.integers(3, cfg.vocab_size, size=n).tolist() for n in (9, 14)]
-        pb_ = [rng.integers(3, cfg.vocab_size, size=n).tolist() for n in (6,)]
-        a = run_reference(model, make_requests(pb2, pa, max_new=10, first_id=0, batch_id=1))
-        steps = [step(model, a, first=True), step(model, a), step(model, a)]
-        b = run_reference(model, make_requests(pb2, pb_, max_new=10, first_id=2, batch_id=2))
-        steps.append(step(model, b, first=True, for_concat=True))
-        with model.context_manager():
-            merged = model.batch_type.concatenate([a, b])
-        steps += [step(model, merged), step(model, merged)]
-        with model.context_manager():
-            merged = model.batch_type.prune(merged, [0])
-        steps += [step(model, merged), step(model, merged)]
+        def continuous():
+            pa = [rng.integers(3, cfg.vocab_size, size=n).tolist() for n in (9, 14)]
+            pb_ = [rng.integers(3, cfg.vocab_size, size=n).tolist() for n in (6,)]
+            a = run_reference(model, make_requests(pb2, pa, max_new=10, first_id=0, batch_id=1))
+            steps = [step(model, a, first=True), step(model, a), step(model, a)]
+            b = run_reference(model, make_requests(pb2, pb_, max_new=10, first_id=2, batch_id=2))
+            steps.append(step(model, b, first=True, for_concat=True))
+            with model.context_manager():
+                merged = model.batch_type.concatenate([a, b])
+            steps += [step(model, merged), step(model, merged)]
+            with model.context_manager():
+                merged = model.batch_type.prune(merged, [0])
+            steps += [step(model, merged), step(model, merged)]
+            return {"prompts_a": pa, "prompts_b": pb_}, steps
+
+        extra, steps = decisive(continuous, f"llama_{variant}_continuous", LLAMA_MARGIN)
         save(f"llama_{variant}_continuous",
-             {**meta_base, "prompts_a": pa, "prompts_b": pb_, "max_new": 10,
+             {**meta_base, **extra, "max_new": 10,
               "script": ["prefill A(ids 0,1)", "decode A", "decode A", "prefill B(id 2, for_concat)",
                          "concatenate[A,B] + decode", "decode", "prune id 0 + decode", "decode"]}, steps)
 
@@ -262,14 +299,21 @@ def main():
     model = get_model(mdir, None, "hf_transformers", "float32", None, 256)
     bmeta = {"variant": "bigcode", "seed": 13, "embed_scale": 3.0, "config": bcfg.to_dict(),
              "transformers": __import__("transformers").__version__, "torch": torch.__version__}
-    prompts = [rng.integers(3, bcfg.vocab_size, size=12).tolist() for _ in range(3)]
-    batch = run_reference(model, make_requests(pb2, prompts, max_new=6))
-    steps = [step(model, batch, first=True)] + [step(model, batch) for _ in range(5)]
-    save("bigcode_equal", {**bmeta, "prompts": prompts, "max_new": 6}, steps)
-    prompts = [rng.integers(3, bcfg.vocab_size, size=n).tolist() for n in (4, 35, 18)]
-    batch = run_reference(model, make_requests(pb2, prompts, max_new=5))
-    steps = [step(model, batch, first=True)] + [step(model, batch) for _ in range(4)]
-    save("bigcode_ragged", {**bmeta, "prompts": prompts, "max_new": 5}, steps)
+    def b_equal():
+        prompts = [rng.integers(3, bcfg.vocab_size, size=12).tolist() for _ in range(3)]
+        batch = run_reference(model, make_requests(pb2, prompts, max_new=6))
+        return {"prompts": prompts}, [step(model, batch, first=True)] + [step(model, batch) for _ in range(5)]
+
+    extra, steps = decisive(b_equal, "bigcode_equal", BIGCODE_MARGIN)
+    save("bigcode_equal", {**bmeta, **extra, "max_new": 6}, steps)
+
+    def b_ragged():
+        prompts = [rng.integers(3, bcfg.vocab_size, size=n).tolist() for n in (4, 35, 18)]
+        batch = run_reference(model, make_requests(pb2, prompts, max_new=5))
+        return {"prompts": prompts}, [step(model, batch, first=True)] + [step(model, batch) for _ in range(4)]
+
+    extra, steps = decisive(b_ragged, "bigcode_ragged", BIGCODE_MARGIN)
+    save("bigcode_ragged", {**bmeta, **extra, "max_new": 5}, steps)
 
     # --- GPTQ pack pin: the reference's own packer vs oracle.ops_ref.gptq_pack on the same integers -----------
     from text_generation_server.utils.gptq.quant_linear import QuantLinear

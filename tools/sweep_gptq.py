@@ -1,10 +1,10 @@
 import os, subprocess, sys
 shapes = [(4096, 12288), (4096, 4096), (4096, 22016), (11008, 4096)]
 plans = {
- (4096,12288): ["2048,2,4,3","4096,1,4,3","4096,1,4,2","2048,2,4,2","2048,2,2,4","1024,4,2,4"],
- (4096,4096): ["1024,4,4,2","1024,4,2,2","2048,2,4,2","2048,2,4,3","1024,4,4,3","512,8,2,4"],
- (4096,22016): ["4096,1,4,3","4096,1,4,4","4096,1,2,4","2048,2,4,3","2048,2,2,4","4096,1,4,2"],
- (11008,4096): ["3072,4,4,2","3072,4,4,3","2048,6,4,2","1536,8,2,2","2048,6,2,4","3072,4,2,4"],
+ (4096,12288): ["2048,2,4,3","4096,1,4,3","4096,1,4,2","2048,2,4,2","2048,2,2,4","1024,4,2,4","2048,2,4,4","4096,1,4,4","1024,4,4,4"],
+ (4096,4096): ["1024,4,4,2","1024,4,2,2","2048,2,4,2","2048,2,4,3","1024,4,4,3","512,8,2,4","512,8,2,2","1024,4,4,4","2048,2,4,4"],
+ (4096,22016): ["4096,1,4,3","4096,1,4,4","4096,1,2,4","2048,2,4,3","2048,2,2,4","4096,1,4,2","4096,1,2,3","4096,1,2,2"],
+ (11008,4096): ["3072,4,4,2","3072,4,4,3","2048,6,4,2","1536,8,2,2","2048,6,2,4","3072,4,2,4","3072,4,4,4","2048,6,4,4","1536,8,4,2","2048,6,4,3"],
 }
 code = '''
 import sys, torch
