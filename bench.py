@@ -312,11 +312,15 @@ def main():
         lm.generate_token(batch, first=True)  # prefill (untimed): fills the KV pages
         return batch
 
+    from tgis_amd.utils import graph_segments
+
     with lm.context_manager():
         batch = fresh_batch()
         for _ in range(W):
             lm.generate_token(batch)
         sync()
+        if tp > 1:
+            graph_segments.time_collectives(True)
         step_ms = []
         t0 = time.perf_counter()
         for _ in range(K):
@@ -329,12 +333,14 @@ def main():
             t = torch.tensor([elapsed], device=device, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
+        coll_us = graph_segments.collective_times_us() if tp > 1 else []
+        graph_segments.time_collectives(False)
         ctx_timed_mean = L_in + 1 + W + (K - 1) / 2.0  # keys attended per step, averaged over the timed steps
         graphs_kept = bool(lm.use_graphs)
         last = next(iter(lm._graphs.values()), None)
         logits_finite = bool(torch.isfinite(last.logits).all()) if last is not None and last.logits is not None else None
 
-        roofline = None
+        roofline = roofline_gemm = None
         if not args.no_roofline:  # every rank runs it (the forward contains collectives when tp > 1)
             # Instrumented pass over the same workload: eager launches (HIP events cannot bracket nodes of a
             # replayed graph), event pairs recorded by libtgis_hip.so on the launch stream around every attention
@@ -365,6 +371,21 @@ def main():
                         "avg_launch_us": round(avg_s * 1e6, 2),
                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
                         "gemm_launches": int(n_gemm), "gemm_avg_launch_us": round(ms_gemm * 1e3 / max(n_gemm, 1), 2)}
+            # the weight-streaming GEMMs (the kernels furthest below their roofline): algorithmic bytes = the packed
+            # weights + scales/zeros they stream (SURVEY.md §8d W_q + W_sz; dense models: W_dense incl. the head),
+            # averaged over the launches of one step
+            abw = algorithmic_bytes_per_step(cfg, quantize, B, ctx_timed_mean, tp)
+            gemm_bytes_step = abw["weights"] + (0 if quantize == "gptq" else abw["head"])
+            per_step = n_gemm / max(K, 1)
+            if n_gemm:
+                g_avg_s = ms_gemm * 1e-3 / n_gemm
+                g_bytes = gemm_bytes_step / max(per_step, 1)
+                roofline_gemm = {"bound": "hbm", "kernel": ("gptq_gemm_kernel" if quantize == "gptq" else "dense_gemm_kernel")
+                                 + f" ({per_step:.0f} launches per step)",
+                                 "achieved": round(g_bytes / g_avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(g_bytes / g_avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                 "launches": int(n_gemm), "avg_launch_us": round(g_avg_s * 1e6, 2),
+                                 "algorithmic_bytes_per_launch": int(g_bytes)}
 
     toks_per_s = B * K / elapsed
     ab = algorithmic_bytes_per_step(cfg, quantize, B, ctx_timed_mean, tp)
@@ -382,12 +403,20 @@ def main():
                    "global_batch": B, "seq_len": int(round(ctx_timed_mean)), "parallelism": f"tp{tp}",
                    "weights": "int4 GPTQ g128" if quantize == "gptq" else dtype_s,
                    "logits_finite": logits_finite,
-                   "hip_graph": (lm.graph_mode if tp > 1 else True) if (graphs_used and graphs_kept) else False},
+                   "hip_graph": (lm.graph_mode if tp > 1 else True) if (graphs_used and graphs_kept) else False,
+                   "rccl_world": (torch.distributed.get_world_size() if tp > 1 else 1),
+                   "collective_backend": (torch.distributed.get_backend() if tp > 1 else None),
+                   # eagerly issued collectives only (segments / eager mode); inside one captured graph they cannot be
+                   # bracketed and are part of ms_per_step
+                   "collectives_per_step": (round(len(coll_us) / K, 1) if coll_us else None),
+                   "collective_avg_us": (round(sum(coll_us) / len(coll_us), 2) if coll_us else None)},
         "step_roofline": {"algorithmic_bytes_per_step": int(ab["total"]), "ms_at_hbm_peak": round(step_roof_ms, 4),
                           "frac_of_hbm_peak": round(step_roof_ms / (elapsed / K * 1e3), 4)},
     }
     if roofline is not None:
         out["roofline"] = roofline
+    if roofline_gemm is not None:
+        out["roofline_gemm"] = roofline_gemm
     if rank == 0 and not args.no_cpu_baseline and world == 1 and not bigcode:  # the CPU port below is the Llama layer
         out["cpu_baseline"] = cpu_baseline(cfg, quantize, B, int(round(ctx_timed_mean)))
     if rank == 0:

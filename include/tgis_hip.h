@@ -87,6 +87,12 @@ int tgis_gptq_prepare(const int32_t* qweight, const int32_t* qzeros, const void*
 
 /* Workspace for split-K partial sums + arrival counters of one gemm call. The counter region
  * (first 4096 bytes) must be zero before the first call; the kernel leaves it zero. */
+/* Largest M for which tgis_gptq_gemm_f16 is a fused dequantise + MFMA kernel worth calling (above it the caller
+ * dequantises once with tgis_gptq_dequant_f16 and uses a library GEMM, exllamav2.py:87 "M > 50"): M <= 64 streams the
+ * weights once per pass, 64 < M <= 256 in 64-row passes, and — for K % 64 == 0, group size 64 * 2^n, no act-order, act != 1 —
+ * a tall kernel (one dequantisation per 128 rows, 700-900 TFLOP/s, no scratch copy of W) takes over up to a few thousand
+ * rows. */
+int64_t tgis_gptq_gemm_fused_rows(int64_t K, int64_t groups, int act_order, int act);
 int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
 
 /* out[M,N] f16 = x[M,K] f16 @ dequant(W)[K,N] (+ bias[N] f16 if non-NULL); fp32 accumulate.

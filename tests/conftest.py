@@ -27,3 +27,18 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a GPU: torch.cuda.is_available() is False")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_memory_between_tests(request):
+    """GPU tests build whole models (one of them with the default KV pool of 85 % of the free memory); what a finished
+    test leaves in the caching allocator must not starve the multi-process tests that follow in the same session."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gc
+
+        import torch
+
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()

@@ -30,6 +30,9 @@ class _GptqWeight:
     def workspace_bytes(self, M):
         return 0
 
+    def fused_rows(self, act=0):
+        return 256
+
 
 class _DenseWeight:
     def __init__(self, weight):

@@ -51,10 +51,20 @@ def test_from_pb_left_truncation_and_bos():
 
 def test_page_ownership_concat_prune_release():
     cache = PagedKVCache(2, 2, 64, 16, torch.float16, CPU)
-    a = _batch([[5] * 30, [6] * 3], 40, batch_id=1)          # 70 and 43 tokens -> 3 + 2 pages
-    a.allocate_pages(cache)
+    a = _batch([[5] * 70, [6] * 33], 40, batch_id=1)         # prompt + first token: 71 and 34 slots -> 3 + 2 pages
+    a.allocate_pages(cache)                                  # (max_output_length 40 reserves nothing up front)
     assert [len(p) for p in a.pages] == [3, 2] and cache.free_pages == 11
     assert a.block_tables.shape == (2, 8) and a.block_tables.dtype == torch.int32
+    # decode growth: a page is taken when a sequence's next token crosses onto it, the table is edited in place
+    a.input_lengths = [96, 34]
+    a.grow_pages()
+    assert [len(p) for p in a.pages] == [3, 2] and cache.free_pages == 11
+    a.input_lengths = [97, 65]
+    a.grow_pages()
+    assert [len(p) for p in a.pages] == [4, 3] and cache.free_pages == 9
+    assert a.block_tables[0, :4].tolist() == a.pages[0] and a.block_tables[1, :3].tolist() == a.pages[1]
+    cache.free([a.pages[0].pop(), a.pages[1].pop()])
+    a.input_lengths = [70, 33]
     b = _batch([[7] * 10], 5, first_id=2, batch_id=2)
     b.allocate_pages(cache)
     a.cu_seqlens_q = torch.arange(3, dtype=torch.int32)
@@ -62,12 +72,12 @@ def test_page_ownership_concat_prune_release():
     m = FlashCausalLMBatch.concatenate([a, b])
     assert a.pages is None and b.pages is None and [len(p) for p in m.pages] == [3, 2, 1]
     assert m.batch_id == 1 and [r.id for r in m.requests] == [0, 1, 2] and cache.free_pages == 10
-    assert m.cu_seqlens.tolist() == [0, 30, 33, 43]
+    assert m.cu_seqlens.tolist() == [0, 70, 103, 113]
     # prune the middle request: its pages return to the pool, logical cu_seqlens are re-packed
-    m.position_ids = torch.tensor([30, 3, 10])
+    m.position_ids = torch.tensor([70, 33, 10])
     kept = FlashCausalLMBatch.prune(m, [1])
     assert kept is m and [r.id for r in m.requests] == [0, 2] and cache.free_pages == 12
-    assert m.cu_seqlens.tolist() == [0, 31, 42]  # cumsum(position + 1): each kept run plus its free slot
+    assert m.cu_seqlens.tolist() == [0, 71, 82]  # cumsum(position + 1): each kept run plus its free slot
     assert FlashCausalLMBatch.prune(m, []) is m
     assert FlashCausalLMBatch.prune(m, [0, 2]) is None and cache.free_pages == 16
     c = _batch([[1] * 600], 10)

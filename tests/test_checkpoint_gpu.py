@@ -31,8 +31,10 @@ def _write_checkpoint(path, cfg, tensors, quantize, groupsize):
 
 
 @pytest.mark.parametrize("quantize", [None, "gptq"])
-def test_checkpoint_directory_end_to_end(gpu_device, tmp_path, quantize):
+def test_checkpoint_directory_end_to_end(gpu_device, tmp_path, quantize, monkeypatch):
     from tgis_amd.models import get_model
+
+    monkeypatch.setenv("TGIS_KV_CACHE_FRACTION", "0.01")  # the default pool (85 % of the free memory) is not the subject
     from tgis_amd.pb import generate_pb2 as pb2
 
     cfg = TinyLlamaConfig()
@@ -70,9 +72,10 @@ def test_checkpoint_directory_end_to_end(gpu_device, tmp_path, quantize):
     assert lm.kv_cache.free_pages == lm.kv_cache.num_pages
 
 
-def test_bigcode_checkpoint_directory_end_to_end(gpu_device, tmp_path):
+def test_bigcode_checkpoint_directory_end_to_end(gpu_device, tmp_path, monkeypatch):
     """GPT-BigCode (multi-query) checkpoint through AutoConfig: field names come from transformers' GPTBigCodeConfig
     (n_embd / n_head / n_layer ...), not from the test's own config class."""
+    monkeypatch.setenv("TGIS_KV_CACHE_FRACTION", "0.01")
     from oracle.santacoder_ref import SantacoderRef
     from oracle.tiny_models import TinyBigCodeConfig, tiny_bigcode_tensors
     from tgis_amd.models import get_model

@@ -348,3 +348,32 @@ def test_decode_attention_at_workload_context(gpu_device, name, B, H, Hkv, D, ct
     err = float((out.float().cpu() - want).abs().max())
     tol = 4e-3 if dtype == torch.float16 else 2.5e-2  # outputs are averages of unit normals (|o| < 0.3): P and O rounding
     assert err <= tol, f"{name}: max err {err:.5f} > {tol} (splits {ns})"
+
+
+@pytest.mark.parametrize("K,N,act", [(4096, 12288, 0), (4096, 22016, 2), (11008, 4096, 0), (4096, 4096, 0)])
+@pytest.mark.parametrize("M", [65, 100, 128, 257, 1000])
+def test_gptq_tall_kernel_matches_oracle(gpu_device, K, N, act, M):
+    """64 < M: the fused tall kernel (one dequantisation per 128 rows, no scratch copy of W) at the cfg3 shapes, every
+    epilogue (plain, split-K + reduce, SiLU * up on the interleaved image, deferred slabs), ragged last row block."""
+    from tgis_amd import native
+
+    qw, qz, sc, gi = ops_ref.make_gptq_tensors(K, N, 128, seed=K + N + M)
+    dev = gpu_device
+    w = native.GptqWeight(torch.from_numpy(qw).to(dev), torch.from_numpy(qz).to(dev), torch.from_numpy(sc).to(dev),
+                          torch.from_numpy(gi), 4, 128, gate_up=(act == 2))
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, K, generator=g) * 0.5).half()
+    bias = (torch.randn(N, generator=g) * 0.1).half()
+    ws = native.Workspace(w.workspace_bytes(M), dev)
+    out = native.gptq_gemm(x.to(dev), w, ws, bias=bias.to(dev), act=act).float().cpu()
+    y = x.float() @ ops_ref.gptq_dequant(qw, qz, sc, gi, 128) + bias.float()
+    want = ops_ref.silu_mul(y.half().float(), N // 2) if act == 2 else y
+    scale = float(want.abs().max())
+    err = float((out - want).abs().max())
+    assert out.shape == want.shape and err <= 3e-3 * scale + 2e-3, f"{K}x{N} act={act} M={M}: max err {err:.5f} (|y| {scale:.3f})"
+    if act == 0 and M <= 256:  # deferred split-K form: the consumer (here: the norm kernel) finishes the sum
+        part = native.gptq_gemm_partial(x.to(dev), w, bias=bias.to(dev))
+        res = torch.zeros(M, N, dtype=torch.float16, device=dev)
+        ynorm, summed = native.rmsnorm_residual(part, res, torch.ones(N, dtype=torch.float16, device=dev), 1e-5)
+        err2 = float((summed.float().cpu() - y).abs().max())
+        assert err2 <= 3e-3 * scale + 2e-3, f"partial form: {err2}"

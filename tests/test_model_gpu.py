@@ -421,3 +421,44 @@ def test_captured_graphs_survive_table_and_workspace_growth(gpu_device):
     for i, (a, b) in enumerate(zip(graphed, eager)):
         assert np.array_equal(a, b), f"step {i}: replayed graph differs from the eager step"
     assert lm.kv_cache.free_pages == lm.kv_cache.num_pages
+
+
+def test_pages_grow_with_the_tokens_and_the_memory_model_is_measured(gpu_device):
+    """KV pages are taken as tokens arrive (prompt + 1 at prefill, one page per 32 generated tokens), so what a batch
+    holds is what the router's token count says it holds — not max_output_length; and the shard's ModelInfo numbers come
+    from a measured prefill activation fit."""
+    from tgis_amd.utils.kv_cache import PagedKVCache
+    from tgis_amd.utils.memory_characterizer import characterize_paged
+
+    cfg = TinyLlamaConfig()
+    tensors = tiny_llama_tensors(cfg, seed=5, quantize="gptq", groupsize=64)
+    lm, tok = _build(cfg, tensors, "gptq", 64, torch.float16)
+    tap = _LogitTap(lm)
+    rng = np.random.default_rng(3)
+    lens = (30, 31, 32, 65)
+    prompts = [rng.integers(3, cfg.vocab_size, size=n).tolist() for n in lens]
+    batch = _from_pb(lm, tok, _pb(prompts, 200))  # max_output_length 200 would have reserved 8 pages per request
+    _step(lm, batch, tap, first=True)
+    assert [len(p) for p in batch.pages] == [PagedKVCache.pages_for(n + 1) for n in lens] == [1, 1, 2, 3]
+    ref = LlamaRef(cfg, tensors, quantize="gptq", groupsize=64)
+    ids = []
+    for s in range(40):
+        toks, _ = _step(lm, batch, tap)
+        ids.append([t.token_id for t in toks])
+        assert [len(p) for p in batch.pages] == [PagedKVCache.pages_for(n + s + 2) for n in lens], f"step {s}"
+    # growing the tables in place keeps the stream the oracle's
+    first = ref.generate_greedy(prompts, 1)[0]["token_ids"].tolist()
+    want = ref.generate_greedy(prompts, 41, forced=[first] + ids)
+    for s in (0, 1, 2, 33, 39):  # around the steps where sequences took a new page
+        assert ids[s] == want[s + 1]["token_ids"].tolist(), f"decode step {s}"
+    held = sum(len(p) for p in batch.pages)
+    batch.release()
+    assert lm.kv_cache.free_pages == lm.kv_cache.num_pages and held < 4 * PagedKVCache.pages_for(65 + 200)
+    msm = characterize_paged(lm, max_sequence_length=256, max_batch_size=4, safety_margin=20)
+    fit = lm.prefill_memory_fit
+    E, I = cfg.hidden_size, cfg.intermediate_size
+    assert fit["bytes_per_token"] >= 2 * (2 * I + E) and fit["max_prefill_tokens"] > 0  # at least gate_up + hidden, fp16
+    pb = msm.as_pb()
+    assert pb.weight_limit == (lm.kv_cache.num_pages - 4) * 32 * 80 // 100 and pb.nexttoken_linear_coef1 == 1.0
+    assert pb.prefill_linear_coef0 >= 1.0
+    assert lm.kv_cache.free_pages == lm.kv_cache.num_pages, "the probes gave their pages back"

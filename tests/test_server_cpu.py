@@ -107,7 +107,8 @@ def test_servicer_lifecycle():
                 assert e.value.code() == grpc.StatusCode.NOT_FOUND
                 # pool exhaustion maps to RESOURCE_EXHAUSTED like a CUDA OOM (server.py:48-51)
                 with pytest.raises(grpc.aio.AioRpcError) as e:
-                    await stub.Prefill(pb.PrefillRequest(batch=pb.Batch(id=9, requests=[_req(8, n=3, max_new=600)])))
+                    # (pages are taken as tokens arrive: a long PROMPT exhausts the 8-page pool, a large max_new does not)
+                    await stub.Prefill(pb.PrefillRequest(batch=pb.Batch(id=9, requests=[_req(8, n=300, max_new=5)])))
                 assert e.value.code() == grpc.StatusCode.RESOURCE_EXHAUSTED
                 await stub.ClearCache(pb.ClearCacheRequest())
                 assert len(svc.cache) == 0 and model.kv_cache.free_pages == 8
@@ -117,3 +118,27 @@ def test_servicer_lifecycle():
             await server.stop(0)
 
     asyncio.run(run())
+
+
+def test_memory_scaling_model_matches_the_routers_arithmetic():
+    """utils/memory_characterizer.py: the paged (token-unit) model admits exactly what the page pool can hold, and the
+    manual models reproduce the reference's percent-of-capacity formulas (memory_characterizer.py:110-143)."""
+    from tgis_amd.utils.memory_characterizer import MemoryScalingModel
+
+    m = MemoryScalingModel.paged(num_pages=1000, max_batch_size=32, safety_margin=20, prefill_tokens_max=8000)
+    pb = m.as_pb()
+    assert pb.weight_limit == (1000 - 32) * 32 * 80 // 100 and pb.nexttoken_linear_coef1 == 1.0
+    assert pb.nexttoken_linear_coef0 == 0.0 and pb.prefill_quadratic_coef1 == 0.0
+    # router: FlashBatch.prefill_weight = tokens * prefill_linear_coef0 <= weight_limit  <=>  tokens <= 8000
+    assert 8000 * pb.prefill_linear_coef0 <= pb.weight_limit * (1 + 1e-6) < 8001 * pb.prefill_linear_coef0
+    # whatever batch the router admits for decode fits the pool even with every request on a partly filled page
+    for B, tokens in ((32, 600), (7, 3000), (1, 24000)):
+        if m.next_token_weight(B, tokens, 0) <= m.weight_limit:
+            assert B * ((tokens + 31) // 32) <= 1000
+    # a prefill can never be cheaper than its own KV
+    assert MemoryScalingModel.paged(1000, 32, 20, 10 ** 9).as_pb().prefill_linear_coef0 == 1.0
+    q = MemoryScalingModel.manual_quadratic(20, max_seq_len=2048, max_batch_size=8).as_pb()
+    assert q.weight_limit == 100 and abs(q.prefill_quadratic_coef1 - 100.0 / (0.8 * 2048 * 2048 * 8)) < 1e-12
+    assert abs(q.nexttoken_linear_coef0 - 100.0 / (0.8 * 2048 * 8)) < 1e-9 and q.nexttoken_linear_coef0 == q.nexttoken_linear_coef1
+    lin = MemoryScalingModel.manual_linear(0, 100, 4)
+    assert lin.prefill_weight(4, 100) == pytest.approx(100.0) and lin.next_token_weight(4, 60, 40) == pytest.approx(100.0)

@@ -96,6 +96,182 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
                                                                                     smem, 0, ring);
 }
 
+// ---- "tall" kernel: 64 < M (decode batches beyond 32 rows, add-on prefills of up to a few thousand tokens) --------
+// The streaming kernel above re-streams and re-dequantises the weights once per 32 (64) rows; the library path
+// (dequantise the whole matrix to a scratch copy, then hipBLASLt) only pays off for very tall M.  In between, one block
+// keeps BM = 32 BMR rows of x in LDS per 128-k chunk and each of its four waves owns one 32-column tile: a wave loads
+// 1 KiB of the same prepared image per k64-step, dequantises it ONCE into four MFMA B fragments and applies them to
+// all BMR row blocks (BMR x 4 MFMAs 32x32x16 per 52 dequantisation instructions: MFMA-bound from BMR = 2).  No scratch
+// copy of W, no second pass over the weights, same epilogues (bias, SiLU * up on the interleaved gate/up image,
+// split-K slabs in the 32-row units the consumers expect).
+constexpr int TKC = 128;       // k per x chunk (2 k64-steps)
+constexpr int TRS = TKC + 8;   // LDS row stride in halves (+16 B: conflict-free ds_read_b128 of A fragments)
+
+template <int BMR, int ACT>
+__global__ __launch_bounds__(256) void gptq_gemm_tall_kernel(GemmArgs a) {
+    constexpr int BM = 32 * BMR;
+    constexpr int NJ = BM * 16 / 256;  // 16-byte x pieces per thread and chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f16* xs = reinterpret_cast<f16*>(smem);  // [2][BM][TRS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * BM;
+    const int mrows = min(BM, a.M - m0);
+    const int split = blockIdx.z;
+    const int nt_raw = blockIdx.x * 4 + w;
+    const int nt = min(nt_raw, a.NT - 1);
+    const int ksteps = a.K >> 6;                     // K % 64 == 0 (host)
+    const int per = a.KR >> 6;                       // k64-steps per split (multiple of 2)
+    const int ks0 = split * per, ks1 = min(ksteps, ks0 + per);
+    const int nchunks = (ks1 - ks0 + 1) >> 1;        // block-uniform
+
+    const char* wtile = reinterpret_cast<const char*>(a.prep) + (int64_t)nt * a.KS * 1024;
+    const char* sztile = reinterpret_cast<const char*>(a.prep + a.offB) + (int64_t)nt * a.G * 128;
+    const uint32_t woff = lane * 16, szoff = (lane & 31) * 4;
+    auto sz_at = [&](int ks) -> uint32_t {
+        const int g = min(ks >> a.spg_shift, a.G - 1);
+        const char* p = sztile + (int64_t)g * 128;
+        PIN_SGPR(p);
+        const uint32_t v = *(const GLOBAL_AS uint32_t*)(p + szoff);
+        return ks < ks1 ? v : 0u;  // steps past the split's range add zeros
+    };
+    auto w_at = [&](int ks) -> u32x4 {
+        const char* p = wtile + (int64_t)min(ks, ksteps - 1) * 1024;
+        PIN_SGPR(p);
+        return __builtin_nontemporal_load((const GLOBAL_AS u32x4*)(p + woff));
+    };
+
+    // x staging: piece p = tid + 256 j -> row p / 16, 8-element column (p % 16) * 8 of the chunk
+    const f16* xbase = a.x + (int64_t)m0 * a.ldx;
+    f16x8 xg[NJ];
+    uint32_t rowoff[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) rowoff[j] = (uint32_t)(min((tid + 256 * j) >> 4, mrows - 1) * (int)a.ldx * 2);
+    const int scol = (tid & 15) * 8;
+    auto stage_load = [&](int chunk) {
+        const int kc = min((ks0 << 6) + chunk * TKC + scol, a.K - 8);
+        const char* xb = reinterpret_cast<const char*>(xbase);
+        PIN_SGPR(xb);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xg[j] = *(const GLOBAL_AS f16x8*)(xb + rowoff[j] + (uint32_t)kc * 2);
+    };
+    auto stage_store = [&](int buf) {
+        f16* dst = xs + buf * (BM * TRS) + (tid >> 4) * TRS + scol;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) st16(dst + j * 16 * TRS, xg[j]);
+    };
+
+    uint32_t EXr = 0x64006400u, M0r = 0x000F000Fu, M1r = 0x00F000F0u;
+    asm volatile("" : "+v"(EXr));
+    asm volatile("" : "+s"(M0r), "+s"(M1r));
+    f32x16 acc[BMR];
+#pragma unroll
+    for (int rb = 0; rb < BMR; ++rb) acc[rb] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int xoff = (lane & 31) * TRS + (lane >> 5) * 32;
+
+    stage_load(0);
+    u32x4 wq[4];
+    uint32_t szr[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) szr[s] = sz_at(ks0 + s);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wq[s] = w_at(ks0 + s);
+    stage_store(0);
+    __syncthreads();
+
+    // one chunk = 2 k64-steps in ring slots SB, SB + 1; the slots are refilled in place two chunks ahead
+    auto chunk_body = [&](const int chunk, auto sb_tag) {
+        constexpr int SB = decltype(sb_tag)::value;
+        const bool more = chunk + 1 < nchunks;  // block-uniform
+        if (more) stage_load(chunk + 1);
+        uint32_t szn[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) szn[s2] = sz_at(ks0 + chunk * 2 + s2 + 4);
+        const f16* xbuf = xs + (chunk & 1) * (BM * TRS) + xoff;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int ks = ks0 + chunk * 2 + s2;
+            const u32x4 cur = wq[SB + s2];
+            const f16x2 szh = __builtin_bit_cast(f16x2, szr[SB + s2]);
+            const f16 zc1 = szh[1];
+            const f16 zd1 = (f16)960.f - zc1;
+            const f16x2 zc = {zc1, zc1}, zd = {zd1, zd1}, sc = {szh[0], szh[0]};
+            f16x8 b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = gptq::dequant8(cur[i], zc, zd, sc, EXr, M0r, M1r);
+            wq[SB + s2] = w_at(ks + 4);
+            const f16* xk = xbuf + s2 * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int rb = 0; rb < BMR; ++rb) {
+                    const f16x8 av = ld16<f16x8>(xk + rb * (32 * TRS) + i * 8);
+                    acc[rb] = mfma32(av, b[i], acc[rb]);
+                }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) szr[SB + s2] = szn[s2];
+        if (more) stage_store((chunk + 1) & 1);
+        __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I2 = std::integral_constant<int, 2>;
+    int chunk = 0;
+    for (; chunk + 1 < nchunks; chunk += 2) {
+        chunk_body(chunk, I0{});
+        chunk_body(chunk + 1, I2{});
+    }
+    if (chunk < nchunks) chunk_body(chunk, I0{});
+
+    // ---- epilogue: lane holds rows m = 32 rb + (r&3) + 8 (r>>2) + 4 (lane>>5) of column n = nt * 32 + (lane & 31) ----
+    if (nt_raw >= a.NT) return;
+    const int c = lane & 31;
+    if (ACT == 2) {
+        const int half = a.N >> 1;
+        const int j = nt * 16 + (c & 15);
+        const int nsrc = (c < 16) ? j : half + j;
+        const float bv = a.bias ? (float)a.bias[nsrc] : 0.f;
+#pragma unroll
+        for (int rb = 0; rb < BMR; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float mine = (float)(f16)(acc[rb][r] + bv);
+                const float other = __shfl_xor(mine, 16, 64);
+                const int m = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (c < 16 && m < mrows) {
+                    const float sl = mine / (1.f + __expf(-mine));
+                    a.out[(int64_t)(m0 + m) * a.ldo + j] = (f16)((float)(f16)sl * other);
+                }
+            }
+        return;
+    }
+    const int n = nt * 32 + c;
+    if (a.S == 1 && !a.partial) {
+        const float bv = a.bias ? (float)a.bias[n] : 0.f;
+#pragma unroll
+        for (int rb = 0; rb < BMR; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < mrows) a.out[(int64_t)(m0 + m) * a.ldo + n] = (f16)(acc[rb][r] + bv);
+            }
+    } else {
+        // slabs in 32-row units [unit][S][32][NP], unit = row / 32 (what norm / rope / the reduce kernel index)
+        const int64_t np = (int64_t)a.NT * 32;
+#pragma unroll
+        for (int rb = 0; rb < BMR; ++rb) {
+            const int unit = blockIdx.y * BMR + rb;
+            if (unit * 32 >= a.M) continue;
+            float* sl = a.slabs + ((int64_t)(unit * a.S + split) * 32) * np + n;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                sl[(int64_t)m * np] = acc[rb][r];
+            }
+        }
+    }
+}
+
 // Sum the S split-K slabs in fixed order (deterministic) and emit f16 (+bias): thread = (row, 4 columns).
 __global__ __launch_bounds__(256) void splitk_reduce_f16_kernel(const float* __restrict__ slabs,
                                                                 const f16* __restrict__ bias, f16* __restrict__ out,
@@ -195,9 +371,117 @@ extern "C" int tgis_gptq_prepare(const int32_t* qweight, const int32_t* qzeros, 
     return TGIS_OK;
 }
 
+// ---- tall kernel: when, and how it is cut ---------------------------------------------------------------------------
+// Rows from which the tall kernel replaces the 64-row streaming passes, and up to which it replaces dequantise + library
+// GEMM.  tools/tall_sweep.py on MI355X, cfg3 shapes (us, tall / passes / library incl. its dequantisation): gate_up M=128
+// 48 / 52 / 164, M=256 75 / 82 / 172, M=512 132 / 164 / 206, M=1024 254 / - / 297, M=2048 466 / - / 510, M=4096 886 / - /
+// 865; qkv M=256 54 / 49 / 85, M=512 74 / 82 / 100, M=1024 127 / - / 135, M=2048 249 / - / 226.  Up to 256 rows the passes
+// (with their deferred split-K sums) stay; from 257 to 3072 rows the tall kernel runs at 700-900 TFLOP/s without a scratch
+// copy of W; above, hipBLASLt on the dequantised copy (1.0-1.1 PFLOP/s) wins.
+static int64_t tall_min_m() {
+    static const int64_t v = getenv("TGIS_TALL_MIN_M") ? atoll(getenv("TGIS_TALL_MIN_M")) : 257;
+    return v;
+}
+static int64_t tall_max_m() {
+    static const int64_t v = getenv("TGIS_TALL_MAX_M") ? atoll(getenv("TGIS_TALL_MAX_M")) : 3072;
+    return v;
+}
+static bool tall_ok(int64_t M, int64_t K, int64_t groups, const int32_t* perm, int act) {
+    if (M < tall_min_m() || perm != nullptr || act == 1 || K % 64 != 0) return false;
+    const int64_t gs = K / groups, spg = gs / 64;
+    return groups == 1 || (gs % 64 == 0 && (spg & (spg - 1)) == 0);
+}
+struct TallPlan {
+    int BMR, S, KR;
+};
+static TallPlan plan_tall(int64_t M, int64_t K, int64_t N, int act) {
+    TallPlan t;
+    t.BMR = M > 64 ? 4 : 2;
+    const int64_t blocks = cdiv64(cdiv64(N, 32), 4) * cdiv64(M, 32 * t.BMR);
+    const int64_t kchunks = cdiv64(K, TKC);
+    int64_t S = 1;
+    if (act != 2 && blocks < 384) S = std::min<int64_t>(std::min<int64_t>(kchunks, 16), cdiv64(512, blocks));
+    if (const char* e = getenv("TGIS_TALL_SPLITS")) S = std::max<int64_t>(1, std::min<int64_t>(kchunks, atoll(e)));
+    if (act == 2) S = 1;
+    int64_t per = cdiv64(kchunks, S);
+    while (S > 1 && (S - 1) * per >= kchunks) --S;
+    t.S = (int)S;
+    t.KR = (int)(per * TKC);
+    return t;
+}
+static int64_t tall_slab_bytes(int64_t M, int64_t N, int S) { return (int64_t)cdiv64(M, 32) * S * 32 * cdiv64(N, 32) * 32 * 4; }
+
+static int launch_tall(const void* x, int64_t ldx, const void* prepared, const void* bias, void* out, int64_t ldo,
+                       int64_t M, int64_t K, int64_t N, int64_t groups, int act, float* slabs, int partial,
+                       const TallPlan& tp, hipStream_t st) {
+    PrepLayout p = prep_layout(K, N, groups);
+    const int64_t gs = K / groups, spg = gs / 64;
+    GemmArgs a;
+    a.x = (const f16*)x;
+    a.ldx = ldx;
+    a.prep = (const uint8_t*)prepared;
+    a.offB = p.offB;
+    a.bias = partial ? nullptr : (const f16*)bias;
+    a.perm = nullptr;
+    a.out = (f16*)out;
+    a.ldo = ldo;
+    a.M = (int)M;
+    a.K = (int)K;
+    a.N = (int)N;
+    a.G = (int)groups;
+    a.gs = (int)gs;
+    a.KR = tp.KR;
+    a.S = tp.S;
+    a.NT = (int)p.NT;
+    a.KS = (int)p.KS;
+    a.slabs = slabs;
+    a.partial = partial;
+    a.spg_shift = 30;
+    a.err = nullptr;
+    if (groups > 1)
+        for (a.spg_shift = 0; (1 << a.spg_shift) < spg; ++a.spg_shift) {}
+    const int BM = 32 * tp.BMR;
+    TGIS_CHECK_ARG(cdiv64(M, BM) <= 65535, "tgis_gptq_gemm: M too large for one launch");
+    dim3 grid((unsigned)cdiv64(p.NT, 4), (unsigned)cdiv64(M, BM), (unsigned)tp.S);
+    const size_t lds = (size_t)2 * BM * TRS * sizeof(f16);
+#define TGIS_TALL(B, A)                                                                                       \
+    do {                                                                                                      \
+        static bool attr = false;                                                                             \
+        if (!attr) {                                                                                          \
+            TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_gemm_tall_kernel<B, A>,                      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * TRS * 2)); \
+            attr = true;                                                                                      \
+        }                                                                                                     \
+        hipLaunchKernelGGL((gptq_gemm_tall_kernel<B, A>), grid, dim3(256), lds, st, a);                       \
+    } while (0)
+    if (tp.BMR == 4) {
+        if (act == 2) TGIS_TALL(4, 2); else TGIS_TALL(4, 0);
+    } else {
+        if (act == 2) TGIS_TALL(2, 2); else TGIS_TALL(2, 0);
+    }
+#undef TGIS_TALL
+    TGIS_CHECK_LAUNCH();
+    if (!partial && tp.S > 1) {
+        const int NP = (int)p.NT * 32;
+        dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 4), 256), (unsigned)cdiv64(M, 32));
+        hipLaunchKernelGGL(splitk_reduce_f16_kernel, rgrid, dim3(256), 0, st, slabs, (const f16*)bias, (f16*)out, ldo,
+                           (int)M, (int)N, NP, tp.S);
+        TGIS_CHECK_LAUNCH();
+    }
+    return TGIS_OK;
+}
+
+extern "C" int64_t tgis_gptq_gemm_fused_rows(int64_t K, int64_t groups, int act_order, int act) {
+    if (K <= 0 || groups <= 0 || K % groups) return 0;
+    static const int32_t some_perm = 0;
+    return tall_ok(tall_min_m(), K, groups, act_order ? &some_perm : nullptr, act) ? std::max<int64_t>(256, tall_max_m()) : 256;
+}
+
 extern "C" int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N) {
     GemmPlan pl = plan_gemm(K, N, 0, M);
-    return 4096 + slab_bytes(M, N, pl.S);
+    int64_t need = 4096 + slab_bytes(M, N, pl.S);
+    if (M >= tall_min_m() && K % 64 == 0) need = std::max(need, 4096 + tall_slab_bytes(M, N, plan_tall(M, K, N, 0).S));
+    return need;
 }
 
 template <int TN, int WK, int ACT, bool G64, bool PERM, int MR>
@@ -322,6 +606,15 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
     TGIS_CHECK_ARG(out, "tgis_gptq_gemm_f16: null out");
     if (M == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (tall_ok(M, K, groups, perm, act)) {
+        const TallPlan tp = plan_tall(M, K, N, act);
+        const int64_t need_t = 4096 + (tp.S > 1 ? tall_slab_bytes(M, N, tp.S) : 0);
+        TGIS_CHECK_ARG(workspace && workspace_bytes >= need_t, "tgis_gptq_gemm_f16: workspace too small (%ld < %ld)",
+                       (long)workspace_bytes, (long)need_t);
+        TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
+        return launch_tall(x, ldx, prepared, bias, out, ldo, M, K, N, groups, act, (float*)((uint8_t*)workspace + 4096), 0,
+                           tp, st);
+    }
     GemmPlan pl = plan_gemm(K, N, act, M);
     TGIS_CHECK_ARG(cdiv64(M, 32) <= 65535, "tgis_gptq_gemm_f16: M too large for one launch");
     int64_t need = 4096 + slab_bytes(M, N, pl.S);
@@ -334,7 +627,9 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
 
 extern "C" int64_t tgis_gptq_gemm_partial_bytes(int64_t M, int64_t K, int64_t N) {
     GemmPlan pl = plan_gemm(K, N, 0, M);
-    return cdiv64(std::max<int64_t>(M, 1), 64) * 2 * pl.S * 32 * cdiv64(N, 32) * 32 * 4;
+    int64_t need = cdiv64(std::max<int64_t>(M, 1), 64) * 2 * pl.S * 32 * cdiv64(N, 32) * 32 * 4;
+    if (M >= tall_min_m() && K % 64 == 0) need = std::max(need, tall_slab_bytes(M, N, plan_tall(M, K, N, 0).S));
+    return need;
 }
 
 extern "C" int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void* prepared, const int32_t* perm,
@@ -344,6 +639,15 @@ extern "C" int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void
     if (rc != TGIS_OK) return rc;
     TGIS_CHECK_ARG(M >= 1 && cdiv64(M, 32) <= 65535, "tgis_gptq_gemm_f16_partial: bad M");
     TGIS_CHECK_ARG(act != 2, "tgis_gptq_gemm_f16_partial: act=2 cannot be deferred");
+    if (tall_ok(M, K, groups, perm, act)) {
+        const TallPlan tp = plan_tall(M, K, N, act);
+        TGIS_CHECK_ARG(slabs && slabs_bytes >= tall_slab_bytes(M, N, tp.S),
+                       "tgis_gptq_gemm_f16_partial: slab buffer too small");
+        if (num_slabs) *num_slabs = tp.S;
+        if (slab_ld) *slab_ld = cdiv64(N, 32) * 32;
+        TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, (hipStream_t)stream);
+        return launch_tall(x, ldx, prepared, nullptr, nullptr, 0, M, K, N, groups, act, slabs, 1, tp, (hipStream_t)stream);
+    }
     GemmPlan pl = plan_gemm(K, N, 0, M);
     TGIS_CHECK_ARG(slabs && slabs_bytes >= tgis_gptq_gemm_partial_bytes(M, K, N),
                    "tgis_gptq_gemm_f16_partial: slab buffer too small");

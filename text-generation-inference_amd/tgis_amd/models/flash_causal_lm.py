@@ -78,8 +78,11 @@ class FlashCausalLMBatch(Batch):
 
     # ---- page ownership --------------------------------------------------------------------------
     def allocate_pages(self, kv_cache: PagedKVCache):
+        """Pages for the prompt and the first generated token.  The cache then grows one page at a time as sequences
+        cross page boundaries (`grow_pages`), like the reference's KV grows with the tokens produced — the router's
+        batch-weight model (router/src/batch_types.rs:46-118) counts tokens present, not max_output_length."""
         assert self.pages is None
-        need = [PagedKVCache.pages_for(t) for t in self.total_lengths]
+        need = [PagedKVCache.pages_for(n + 1) for n in self.input_lengths]
         flat = kv_cache.alloc(sum(need))  # raises OutOfPages before anything is taken
         self.kv_cache = kv_cache
         self.pages, o = [], 0
@@ -88,12 +91,31 @@ class FlashCausalLMBatch(Batch):
             o += n
         self._rebuild_block_tables()
 
+    def grow_pages(self):
+        """Before a decode step: every sequence owns the page its next token (position input_length - 1) lands on."""
+        short = [i for i, (p, n) in enumerate(zip(self.pages, self.input_lengths)) if len(p) * PAGE < n]
+        if not short:
+            return
+        flat = self.kv_cache.alloc(len(short))  # all or nothing: OutOfPages leaves the batch as it was
+        for i, pg in zip(short, flat):
+            self.pages[i].append(pg)
+        width = self.block_tables.shape[1]
+        if max(len(self.pages[i]) for i in short) > width or getattr(self, "_bt_host", None) is None:
+            self._rebuild_block_tables()
+        else:  # edit the host copy and upload the few KB again (the same copy the prefill made: nothing new to load)
+            for i in short:
+                self._bt_host[i, len(self.pages[i]) - 1] = self.pages[i][-1]
+            self.block_tables = torch.from_numpy(self._bt_host).to(self.block_tables.device, non_blocking=True)
+
     def _rebuild_block_tables(self):
-        width = max(len(p) for p in self.pages)
+        # as wide as the longest sequence can ever get (pages themselves are taken lazily): the decode graph of a batch
+        # is keyed by (size, table width), so the width must not creep up while the batch generates
+        width = max(max(len(p) for p in self.pages), max(PagedKVCache.pages_for(t) for t in self.total_lengths))
         width = (width + 7) // 8 * 8  # few distinct widths -> few captured graphs
         bt = np.zeros((len(self.pages), width), dtype=np.int32)
         for i, p in enumerate(self.pages):
             bt[i, :len(p)] = p
+        self._bt_host = bt
         self.block_tables = torch.from_numpy(bt).to(self.cu_seqlens.device, non_blocking=True)
 
     def release(self):
@@ -521,6 +543,7 @@ class FlashCausalLM(Model):
                                   batch.max_seqlen, batch.inputs_embeds, kv, lm_head_indices)
 
     def _decode_forward(self, batch: FlashCausalLMBatch):
+        batch.grow_pages()
         key = (len(batch), batch.block_tables.shape[1])
         g = self._graphs.get(key)
         if g is None:

@@ -54,6 +54,7 @@ SIGNATURES = {
     "tgis_timing_read": (_c_int, [_c_int, ctypes.POINTER(_c_i64), ctypes.POINTER(ctypes.c_double)]),
     "tgis_gptq_prepared_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
     "tgis_gptq_prepare": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _vp]),
+    "tgis_gptq_gemm_fused_rows": (_c_i64, [_c_i64, _c_i64, _c_int, _c_int]),
     "tgis_gptq_gemm_workspace_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
     "tgis_gptq_gemm_f16": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64,
                                     _c_int, _vp, _c_i64, _vp]),
@@ -248,6 +249,10 @@ class GptqWeight:
 
     def workspace_bytes(self, M: int) -> int:
         return load_library().tgis_gptq_gemm_workspace_bytes(M, self.K, self.N)
+
+    def fused_rows(self, act: int = 0) -> int:
+        """Largest M the fused kernels of tgis_gptq_gemm_f16 should be given (beyond: dequantise + library GEMM)."""
+        return load_library().tgis_gptq_gemm_fused_rows(self.K, self.groups, int(self.perm is not None), act)
 
 
 def gptq_gemm(x: torch.Tensor, w: GptqWeight, ws: Workspace, bias=None, act: int = 0, out=None) -> torch.Tensor:

@@ -5,7 +5,8 @@ router (drop-in boundary #1).  Mirrors server.py:65-231,251-460 
   for_concat=len(cache) > 0)`, cache it unless it is the healthcheck batch (id 2^64-1);
 * NextToken: pop the cached batches, prune by `completed_ids` (absent status = whole batch finished), concatenate,
   `generate_token`, cache; empty response when everything finished; leftover cached batches are cleared with a warning;
-* ModelInfo: CAUSAL_LM, eos id, batch_padding=False (flash/var-len batches), memory scaling model;
+* ModelInfo: CAUSAL_LM, eos id, batch_padding (False for flash/var-len batches), memory scaling model
+  (utils/memory_characterizer.py: token-unit weights of the paged pool + a measured prefill activation fit);
 * OOM -> RESOURCE_EXHAUSTED (a KV-pool exhaustion counts as OOM); PrefixLookup -> NOT_FOUND (no prefix store yet).
 The shard never decides termination: it keeps generating for a row until the router reports it completed."""
 import asyncio
@@ -21,6 +22,7 @@ from tgis_amd.cache import Cache
 from tgis_amd.models.model import Model
 from tgis_amd.pb import generate_pb2, generate_pb2_grpc
 from tgis_amd.utils.kv_cache import OutOfPages
+from tgis_amd.utils.memory_characterizer import ESTIMATE_MEMORY, MemoryScalingModel, characterize_paged
 
 HEALTHCHECK_BATCH_ID = (1 << 64) - 1
 COMPACT_BEFORE_PREFILL = os.getenv("COMPACT_BEFORE_PREFILL", "true") != "false"
@@ -41,22 +43,6 @@ def log_rpc_handler_errors(func):
 
     wrapped.__name__ = func.__name__
     return wrapped
-
-
-class MemoryScalingModel:
-    """Linear/quadratic batch-weight model the router uses for admission (utils/memory_characterizer.py:42-143).
-    With a paged KV pool the decode cost is exactly linear in tokens: weight_limit = pool capacity in tokens."""
-
-    def __init__(self, free_tokens: int, prefill_bytes_per_token: float = 1.0):
-        self.weight_limit = int(free_tokens)
-        self.next_token_params = (0.0, 1.0)
-        self.prefill_params = (1.0, 0.0, 0.0)
-
-    def as_pb(self):
-        return generate_pb2.MemoryScalingModel(
-            prefill_linear_coef0=self.prefill_params[0], prefill_quadratic_coef0=self.prefill_params[1],
-            prefill_quadratic_coef1=self.prefill_params[2], nexttoken_linear_coef0=self.next_token_params[0],
-            nexttoken_linear_coef1=self.next_token_params[1], weight_limit=self.weight_limit)
 
 
 class TextGenerationService(generate_pb2_grpc.TextGenerationServiceServicer):
@@ -80,7 +66,8 @@ class TextGenerationService(generate_pb2_grpc.TextGenerationServiceServicer):
         return generate_pb2.ModelInfoResponse(
             model_type=generate_pb2.ModelInfoResponse.ModelType.Value("CAUSAL_LM"),
             eos_token=getattr(tok, "model_eos_token_id", tok.eos_token_id),
-            batch_padding=False,  # var-len (flash) batches: the router uses its FlashBatch weights
+            # var-len (flash) batches -> the router's FlashBatch weights; padded CausalLM batches -> PaddedBatch (:92)
+            batch_padding=getattr(self.model, "kv_cache", None) is None,
             memory_scaling_model=self.memory_scaling_model.as_pb())
 
     @log_rpc_handler_errors
@@ -201,9 +188,14 @@ def serve(model_name: str, revision: Optional[str], deployment_framework: str, d
             from tgis_amd.models import get_model
 
             model = get_model(model_name, revision, deployment_framework, dtype_str, quantize, max_sequence_length)
-        kvc = getattr(model, "kv_cache", None)
-        free_tokens = kvc.num_pages * 32 if kvc is not None else max_batch_size * max_sequence_length
-        msm = MemoryScalingModel(free_tokens * (100 - batch_safety_margin) // 100)
+        if getattr(model, "kv_cache", None) is not None:
+            # paged KV: token-unit weights, prefill activation peak measured with two synthetic prefills
+            msm = characterize_paged(model, max_sequence_length, max_batch_size, batch_safety_margin)
+        elif ESTIMATE_MEMORY == "off":
+            msm = MemoryScalingModel.disabled()
+        else:  # padded batches on a library model: the reference's manual model (memory_characterizer.py:110-128)
+            msm = MemoryScalingModel.manual_quadratic(batch_safety_margin, max_sequence_length, max_batch_size)
+        print(f"Memory scaling model: {msm.as_pb()}".replace("\n", " "), flush=True)
         server = grpc.aio.server()
         generate_pb2_grpc.add_TextGenerationServiceServicer_to_server(
             TextGenerationService(model, Cache(), server_urls, msm), server)

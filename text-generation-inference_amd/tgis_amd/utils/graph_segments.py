@@ -16,10 +16,39 @@ import torch
 
 _recording: Optional["SegmentedGraph"] = None
 
+# Optional per-collective timing (bench.py --gpus N): event pairs on the launching stream around every collective that
+# is issued eagerly — the uncaptured step and the seams of a segmented graph.  Collectives captured INSIDE a graph
+# (`full` mode) cannot be bracketed; they show up in the step time only.
+_timed: Optional[List] = None
+
+
+def time_collectives(on: bool) -> None:
+    global _timed
+    _timed = [] if on else None
+
+
+def collective_times_us() -> List[float]:
+    """Durations of the collectives timed since time_collectives(True) (synchronises)."""
+    if not _timed:
+        return []
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) * 1e3 for a, b in _timed]
+
+
+def _run_timed(fn: Callable[[], None]) -> None:
+    if _timed is None or torch.cuda.is_current_stream_capturing():
+        fn()
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    fn()
+    b.record()
+    _timed.append((a, b))
+
 
 def collective(fn: Callable[[], None]) -> None:
     if _recording is None:
-        fn()
+        _run_timed(fn)
     else:
         _recording._seam(fn)
 
@@ -84,7 +113,7 @@ class SegmentedGraph:
             if isinstance(it, torch.cuda.CUDAGraph):
                 it.replay()
             else:
-                it()
+                _run_timed(it)
 
     @property
     def num_segments(self) -> int:

@@ -18,8 +18,9 @@ from tgis_amd.utils.graph_segments import collective
 
 import os
 
-# rows up to which the weight-streaming MFMA kernels are used (one pass over the weights per 32 rows); above, dequant +
-# hipBLASLt.  Measured crossover on cfg3 shapes: ~13 us per 32-row slab vs ~170 us per GEMM for the dequant path.
+# rows up to which the dense weight-streaming MFMA kernel is used (one pass over the weights per 32 / 64 rows); above,
+# hipBLASLt.  GPTQ linears ask the library how far its fused kernels reach (GptqWeight.fused_rows: 64-row streaming passes
+# to 256 rows, then the tall fused kernel to ~3k rows; beyond that dequantise once + hipBLASLt, exllamav2.py:87).
 SKINNY_MAX_M = int(os.getenv("TGIS_SKINNY_MAX_M", "256"))
 # fuse the split-K reduce of decode-sized GPTQ GEMMs into the consumer kernel (rmsnorm / rope+KV write)
 DEFER_REDUCE = os.getenv("TGIS_DEFER_REDUCE", "true").lower() not in ("0", "false")
@@ -75,11 +76,18 @@ class Ex4bitLinearV2:
         self.q_handle: Optional[native.GptqWeight] = None
         # set by LlamaMLP on the fused [gate | up] projection: SiLU(gate)*up runs in the GEMM epilogue
         self.gate_up = False
+        self._fused = {}  # act -> rows up to which the library's fused kernels are used
 
     def post_init(self):
         self.q_handle = native.GptqWeight(self.qweight, self.qzeros, self.scales, self.g_idx, self.bits,
                                           self.groupsize, gate_up=self.gate_up)
         self.qweight = self.qzeros = self.scales = None  # the prepared image replaces them
+
+    def _fused_rows(self, act: int) -> int:
+        got = self._fused.get(act)
+        if got is None:
+            got = self._fused[act] = self.q_handle.fused_rows(act)
+        return got
 
     def _dequant_scratch(self) -> torch.Tensor:
         key = (str(self.device), self.height, self.width)
@@ -96,12 +104,12 @@ class Ex4bitLinearV2:
             self.post_init()
         if self.gate_up:
             # output is the activated [M, I] tensor
-            if x.shape[0] <= SKINNY_MAX_M:
+            if x.shape[0] <= self._fused_rows(2):
                 return native.gptq_gemm(x, self.q_handle, workspace(x.device), bias=self.bias, act=2)
             return native.act_mul(self._large_m(x), self.width // 2)
         if partial and x.shape[0] <= native.PARTIAL_MAX_M and DEFER_REDUCE:
             return native.gptq_gemm_partial(x, self.q_handle, bias=self.bias, act=act)
-        if x.shape[0] <= SKINNY_MAX_M:
+        if x.shape[0] <= self._fused_rows(act):
             return native.gptq_gemm(x, self.q_handle, workspace(x.device), bias=self.bias, act=act)
         if act:
             x = native.act_mul(x, self.height)
@@ -173,14 +181,15 @@ class TensorParallelHead(SuperLayer):
         if not self.should_gather:
             return local
         world = self.process_group.size()
-        # gather [V/tp, T] blocks (layers.py:244-269), then hand out row-major [T, V]: the fused argmax/logprob
-        # kernel and the warpers read contiguous rows
-        gather_in = local.t().contiguous()
-        world_out = torch.empty((gather_in.shape[0] * world, gather_in.shape[1]), dtype=local.dtype,
-                                device=local.device)
+        # Every rank contributes its [T, V/tp] block; the gathered [tp, T, V/tp] buffer is re-laid out ONCE into the
+        # row-major [T, V] the fused argmax / warper kernels read.  (The reference gathers transposed [V/tp, T] blocks
+        # and returns a transposed view, layers.py:244-269 — two transposing copies on this side of the gather.)
+        local = local.contiguous()
+        T, vp = local.shape
+        gathered = torch.empty((world, T, vp), dtype=local.dtype, device=local.device)
         pg = self.process_group
-        collective(lambda o=world_out, i=gather_in: torch.distributed.all_gather_into_tensor(o, i, group=pg))
-        return world_out.t().contiguous()
+        collective(lambda o=gathered, i=local: torch.distributed.all_gather_into_tensor(o.view(world * T, vp), i, group=pg))
+        return gathered.permute(1, 0, 2).reshape(T, world * vp)
 
     __call__ = forward
 
