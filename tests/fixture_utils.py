@@ -37,6 +37,7 @@ class FixtureTokenizer:
         self.bos_token_id = 1
         self.eos_token_id = 2
         self.add_bos_token = False
+        self.probe_word = "t5"  # a word of this vocabulary, for the shard's synthetic start-up prefills
 
     def __call__(self, texts, truncation=True, max_length=None, return_token_type_ids=False, **kw):
         out = []

@@ -445,7 +445,8 @@ def test_pages_grow_with_the_tokens_and_the_memory_model_is_measured(gpu_device)
     for s in range(40):
         toks, _ = _step(lm, batch, tap)
         ids.append([t.token_id for t in toks])
-        assert [len(p) for p in batch.pages] == [PagedKVCache.pages_for(n + s + 2) for n in lens], f"step {s}"
+        # decode step s writes position n + s: the page under it is taken at that step, not earlier
+        assert [len(p) for p in batch.pages] == [PagedKVCache.pages_for(n + s + 1) for n in lens], f"step {s}"
     # growing the tables in place keeps the stream the oracle's
     first = ref.generate_greedy(prompts, 1)[0]["token_ids"].tolist()
     want = ref.generate_greedy(prompts, 41, forced=[first] + ids)

@@ -81,7 +81,8 @@ def measure_prefill_peak(model, tokens_per_request: int, requests: int) -> int:
     'test ' repeated, truncated to input_length, greedy)."""
     import torch
 
-    reqs = [generate_pb2.Request(id=i, inputs="test " * (tokens_per_request + 8), input_length=tokens_per_request,
+    word = getattr(model.tokenizer, "probe_word", "test")  # test tokenizers with a closed vocabulary name one of theirs
+    reqs = [generate_pb2.Request(id=i, inputs=f"{word} " * (tokens_per_request + 8), input_length=tokens_per_request,
                                  truncate=True, max_output_length=1) for i in range(requests)]
     pb = generate_pb2.Batch(id=0, requests=reqs, total_tokens=tokens_per_request * requests)
     torch.cuda.synchronize(model.device)
