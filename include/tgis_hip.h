@@ -123,10 +123,16 @@ int tgis_gptq_dequant_f16(const void* prepared, void* w_out, int64_t K, int64_t 
 /* ---- dense skinny GEMM (replaces F.linear / torch.mm at decode sizes, utils/layers.py:110-111,
  *      lm_head utils/layers.py:261) -------------------------------------------------------------- */
 int64_t tgis_dense_prepared_bytes(int64_t N, int64_t K);
-/* Repack a torch-Linear weight W[N,K] (row-major, dtype) into 32-column MFMA tiles. */
-int tgis_dense_prepare(const void* w, int64_t N, int64_t K, int dtype, void* prepared, void* stream);
+/* Repack a torch-Linear weight W[N,K] (row-major, dtype) into 32-column MFMA tiles.
+ * flags bit 0: W is the Llama MLP's [gate rows | up rows] (N = 2 I, I a multiple of 16): tile t then holds gate rows
+ * 16 t .. 16 t + 15 and the matching up rows, for the act = 2 epilogue of tgis_dense_gemm. */
+int tgis_dense_prepare(const void* w, int64_t N, int64_t K, int dtype, int flags, void* prepared, void* stream);
 int64_t tgis_dense_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
-/* out[M,N] = x[M,K] @ W^T (+bias).  out_f32 != 0 writes float32 output (logits). */
+/* out[M,N] = x[M,K] @ W^T (+bias).  out_f32 != 0 writes float32 output (logits).
+ * act 0: plain.  act 1: x is [M, 2K] (gate | up) and the operand is silu(gate) * up, formed while it is staged
+ * (down_proj after an un-fused gate_up).  act 2: the image has flags bit 0 and out is [M, N/2] =
+ * silu(x @ Wgate^T) * (x @ Wup^T), each factor rounded to the model dtype as the reference's eager ops do
+ * (flash_llama_modeling.py:332-335); the down projection then runs with act 0. */
 int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared, const void* bias, void* out,
                     int64_t ldo, int64_t M, int64_t K, int64_t N, int dtype, int out_f32, int act,
                     void* workspace, int64_t workspace_bytes, void* stream);
@@ -191,7 +197,7 @@ int tgis_rope_kv_write_prefill(void* qkv, int64_t ld_qkv, const void* cos, const
  *      utils/flash_attn.py:43-78) ---------------------------------------------------------------- */
 /* Number of key-range splits the launcher will use for this shape (so callers can size workspace). */
 int tgis_attn_num_splits(int64_t B, int Hkv, int H, int64_t max_q_len, int64_t max_ctx);
-int64_t tgis_attn_workspace_bytes(int64_t total_q_tokens, int H, int D, int num_splits);
+int64_t tgis_attn_workspace_bytes(int64_t total_q_tokens, int H, int Hkv, int D, int num_splits);
 /* Causal softmax(q k^T * scale) v over the paged cache.
  *   q: [total_q, H, D] with token stride ld_q (elements); out: [total_q, H*D] contiguous.
  *   cu_seqlens_q [B+1] int32: q token offsets per sequence (decode: arange).
@@ -250,22 +256,23 @@ int tgis_warp_sample(const float* logits, int64_t ld_logits, float* scores, int6
                      void* stream);
 
 /* ---- persistent decode tail of a Llama layer --------------------------------------------------------------------
- * Everything the decode step runs between two attention launches, in ONE launch (fp16, int4 GPTQ linears, M <= 32
- * rows, one shard):  o_proj -> add + RMSNorm -> gate_up (SiLU * up) -> down -> add + RMSNorm [-> qkv of the NEXT
- * layer -> rotary + KV-cache write of the next layer].  Replaces, with bit-identical results, the call sequence
+ * Everything the decode step runs between two attention launches, in ONE launch (M <= 32 rows, one shard; either
+ * int4 GPTQ linears in fp16, or dense f16 / bf16 linears):  o_proj -> add + RMSNorm -> gate_up (SiLU * up) -> down ->
+ * add + RMSNorm [-> qkv of the NEXT layer -> rotary + KV-cache write of the next layer].  Dense layers go through the
+ * same chain with tgis_dense_gemm(act = 2) / tgis_dense_gemm_partial.  Replaces, with bit-identical results, the call sequence
  * tgis_gptq_gemm_f16_partial / tgis_rmsnorm_residual_partial / tgis_gptq_gemm_f16(act=2) /
  * tgis_gptq_gemm_f16_partial / tgis_rmsnorm_residual_partial / tgis_gptq_gemm_f16_partial /
  * tgis_rope_kv_write_partial, i.e. the reference's FlashLlamaLayer tail + the next layer's head
  * (custom_modeling/flash_llama_modeling.py:285-297,383-385,332-335,368,251-282).  One workgroup per CU stays resident
  * for the whole launch; the phases are separated by grid barriers (8 group counters -> top counter -> 8 generation
  * words, relaxed agent-scope polling, every spin bounded) and hand their results over as sc1 write-through stores /
- * sc1 loads.  All buffers are caller-owned; slab buffers hold tgis_llama_decode_tail_slab_bytes(M, K, N) bytes.
+ * sc1 loads.  All buffers are caller-owned; slab buffers hold tgis_llama_decode_tail_slab_bytes(M, K, N, groups) bytes.
  * `qkv.prepared == NULL` ends the launch after the second norm (last layer: norm2_weight is then the final norm).
  * The GPU must not be shared with another process's persistent launch (tensor-parallel ranks on one device). */
 typedef struct tgis_tail_linear {
-    const void* prepared; /* image made by tgis_gptq_prepare (gate_up: with flags bit 0) */
-    const void* bias;     /* f16 [N] or NULL */
-    int64_t K, N, groups;
+    const void* prepared; /* image made by tgis_gptq_prepare or tgis_dense_prepare (gate_up: with flags bit 0) */
+    const void* bias;     /* T [N] or NULL */
+    int64_t K, N, groups; /* groups == 0: a dense f16 / bf16 image (all four linears of a layer are of one kind) */
 } tgis_tail_linear;
 
 typedef struct tgis_tail_args {
@@ -292,9 +299,12 @@ typedef struct tgis_tail_args {
     void* k_pool;             /* next layer's pools (see tgis_rope_kv_write) */
     void* v_pool;
     int H, Hkv, D, rot_dim;
+    int dtype; /* TGIS_F16 / TGIS_BF16: element type T of every activation, norm weight, cos / sin table and KV pool
+                * (int4 layers: TGIS_F16) */
 } tgis_tail_args;
 
-int64_t tgis_llama_decode_tail_slab_bytes(int64_t M, int64_t K, int64_t N);
+/* bytes of one slab buffer (slabs_o / slabs_down / slabs_qkv) for a linear of this shape; groups as in tgis_tail_linear */
+int64_t tgis_llama_decode_tail_slab_bytes(int64_t M, int64_t K, int64_t N, int64_t groups);
 /* 1 if the tail can run a layer of these shapes: only M, hidden and K / N / groups of the four linears are read
  * (qkv.K == 0 asks about a last layer).  The kernel exists for the plan signatures listed in csrc/decode_tail.hip. */
 int tgis_llama_decode_tail_fits(const tgis_tail_args* shapes);

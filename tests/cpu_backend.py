@@ -35,9 +35,10 @@ class _GptqWeight:
 
 
 class _DenseWeight:
-    def __init__(self, weight):
+    def __init__(self, weight, gate_up=False):
         self.N, self.K = weight.shape
         self.dtype = weight.dtype
+        self.flags = 1 if gate_up else 0
         self.w = weight.float().t().contiguous()
 
     def workspace_bytes(self, M):
@@ -60,10 +61,12 @@ def _gptq_gemm(x, w, ws, bias=None, act=0, out=None):
 
 
 def _dense_gemm(x, w, ws, bias=None, out_f32=False, act=0, out=None):
-    xf = _act(x, w.K) if act else x.float()
+    xf = _act(x, w.K) if act == 1 else x.float()
     y = xf @ w.w
     if bias is not None:
         y = y + bias.float()
+    if act == 2:
+        return ops_ref.silu_mul(y.to(w.dtype), w.N // 2).to(w.dtype)
     return y if out_f32 else y.to(w.dtype)
 
 

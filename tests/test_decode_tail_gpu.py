@@ -6,6 +6,8 @@ every step, token ids, and the KV pages the fused launch wrote for the next laye
 workgroups (a stale line read after a barrier) shows up as a difference in some step, so the comparison is repeated
 over many decode steps on buffers that are re-used every layer — the situation in which a missing write-through or an
 L1 hit on another CU's data goes wrong — and the launch's own barrier-timeout flag must stay clear."""
+import gc
+
 import numpy as np
 import pytest
 import torch
@@ -13,7 +15,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _build(cfg_kw, layers, seed, use_tail, monkeypatch, B, L, steps):
+def _build(cfg_kw, layers, seed, use_tail, monkeypatch, B, L, steps, quantize="gptq", dtype=torch.float16):
     monkeypatch.setenv("TGIS_DECODE_TAIL", "true" if use_tail else "false")
     import importlib
 
@@ -25,11 +27,11 @@ def _build(cfg_kw, layers, seed, use_tail, monkeypatch, B, L, steps):
 
     M.DECODE_TAIL = use_tail
     cfg = M.LlamaConfig(num_hidden_layers=layers, max_position_embeddings=4096, **cfg_kw)
-    tensors = llama_tensors(cfg, "gptq", seed=seed, device="cpu", dtype=torch.float16)
+    tensors = llama_tensors(cfg, quantize, seed=seed, device="cpu", dtype=dtype)
     tok = FixtureTokenizer(cfg.vocab_size)
-    eng = InferenceEngine(tensors, cfg, torch.float16, "gptq", tokenizer=tok)
+    eng = InferenceEngine(tensors, cfg, dtype, quantize, tokenizer=tok)
     pages = B * PagedKVCache.pages_for(L + steps + 2) + 8
-    lm = FlashCausalLM("tail", None, "synthetic", torch.float16, "gptq", engine=eng, kv_cache_pages=pages)
+    lm = FlashCausalLM("tail", None, "synthetic", dtype, quantize, engine=eng, kv_cache_pages=pages)
     return lm, tok, cfg
 
 
@@ -45,27 +47,33 @@ def _run(lm, tok, prompts, steps):
 
 LLAMA_7B = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_attention_heads=32,
                 num_key_value_heads=32, rms_norm_eps=1e-5)
-SMALL_GQA = dict(vocab_size=1024, hidden_size=1024, intermediate_size=2816, num_attention_heads=16,
+TINYLLAMA = dict(vocab_size=32000, hidden_size=2048, intermediate_size=5632, num_attention_heads=32,
                  num_key_value_heads=4, rms_norm_eps=1e-5)
 
 
-@pytest.mark.parametrize("name,cfg_kw,layers,B,L,steps", [
-    ("llama-7b width, 3 layers, B=32", LLAMA_7B, 3, 32, 40, 24),
-    ("llama-7b width, 2 layers, B=5", LLAMA_7B, 2, 5, 70, 12),
-    ("llama-7b width, 4 layers, B=17", LLAMA_7B, 4, 17, 33, 40),
+@pytest.mark.parametrize("name,cfg_kw,layers,B,L,steps,quantize,dtype", [
+    ("llama-7b width, 3 layers, B=32", LLAMA_7B, 3, 32, 40, 24, "gptq", torch.float16),
+    ("llama-7b width, 2 layers, B=5", LLAMA_7B, 2, 5, 70, 12, "gptq", torch.float16),
+    ("llama-7b width, 4 layers, B=17", LLAMA_7B, 4, 17, 33, 40, "gptq", torch.float16),
+    # dense layers (TinyLlama-1.1B width, GQA 8:1, D = 64): SiLU * up runs in down's operand staging
+    ("tinyllama width bf16, 4 layers, B=16", TINYLLAMA, 4, 16, 40, 40, None, torch.bfloat16),
+    ("tinyllama width f16, 3 layers, B=32", TINYLLAMA, 3, 32, 33, 24, None, torch.float16),
+    ("tinyllama width bf16, 2 layers, B=3", TINYLLAMA, 2, 3, 70, 12, None, torch.bfloat16),
 ])
-def test_tail_is_bit_identical_to_separate_launches(gpu_device, monkeypatch, name, cfg_kw, layers, B, L, steps):
+def test_tail_is_bit_identical_to_separate_launches(gpu_device, monkeypatch, name, cfg_kw, layers, B, L, steps,
+                                                    quantize, dtype):
     from tgis_amd import native
 
     rng = np.random.default_rng(11)
     prompts = [rng.integers(3, cfg_kw["vocab_size"], size=L).tolist() for _ in range(B)]
-    lm_t, tok, _ = _build(cfg_kw, layers, 77, True, monkeypatch, B, L, steps)
+    lm_t, tok, _ = _build(cfg_kw, layers, 77, True, monkeypatch, B, L, steps, quantize, dtype)
     got_t, kv_t, pages_t = _run(lm_t, tok, prompts, steps)
     assert lm_t.model.model._tails, "the tail path was not taken"
     assert native.decode_tail_status() == 0, "a grid barrier of the tail timed out"
     del lm_t
+    gc.collect()  # the model and its captured graphs form a cycle: free them now, not in the middle of the next run
     torch.cuda.empty_cache()
-    lm_s, tok, _ = _build(cfg_kw, layers, 77, False, monkeypatch, B, L, steps)
+    lm_s, tok, _ = _build(cfg_kw, layers, 77, False, monkeypatch, B, L, steps, quantize, dtype)
     got_s, kv_s, pages_s = _run(lm_s, tok, prompts, steps)
     assert not lm_s.model.model._tails
     assert pages_t == pages_s

@@ -339,7 +339,7 @@ def test_decode_attention_at_workload_context(gpu_device, name, B, H, Hkv, D, ct
     q = torch.randn(B, H * D, generator=g).to(dtype)
     out = torch.empty(B, H * D, dtype=dtype, device=dev)
     ns = native.attn_num_splits(B, Hkv, H, 1, max(lens))
-    ws = native.Workspace(max(4096, native.attn_workspace_bytes(B, H, D, ns)), dev)
+    ws = native.Workspace(max(4096, native.attn_workspace_bytes(B, H, Hkv, D, ns)), dev)
     native.attn_paged(q.to(dev), H * D, cache.k_pool(0), cache.v_pool(0), bt,
                       torch.tensor(lens, dtype=torch.int32, device=dev), torch.arange(B + 1, dtype=torch.int32, device=dev),
                       out, B, H, Hkv, D, 1, max(lens), D ** -0.5, ns, ws if ns > 1 else None)

@@ -225,7 +225,7 @@ def test_rope_kv_attention_prefill_then_decode(nat, gpu_device, dtype, H, Hkv, D
     cuq1 = torch.arange(B + 1, dtype=torch.int32, device=gpu_device)
     for ns in (1, 2, 3):
         out1 = torch.empty((B, H * D), dtype=dtype, device=gpu_device)
-        ws = nat.Workspace(nat.attn_workspace_bytes(B, H, D, ns), gpu_device)
+        ws = nat.Workspace(nat.attn_workspace_bytes(B, H, Hkv, D, ns), gpu_device)
         nat.attn_paged(dq1, dq1.stride(0), kpool, vpool, bt.to(gpu_device), ctx1, cuq1, out1, B, H, Hkv, D, 1,
                        max(lens) + 1, D ** -0.5, ns, ws)
         _close(out1.view(B, H, D), want1, rtol=tol, atol=tol, what=f"decode attention splits={ns}")
@@ -258,11 +258,59 @@ def test_attention_decode_long_context(nat, gpu_device):
                                     torch.arange(B + 1), cu, D ** -0.5)
     out = torch.empty((B, H * D), dtype=dtype, device=gpu_device)
     ns = nat.attn_num_splits(B, Hkv, H, 1, max(lens))
-    ws = nat.Workspace(nat.attn_workspace_bytes(B, H, D, ns), gpu_device)
+    ws = nat.Workspace(nat.attn_workspace_bytes(B, H, Hkv, D, ns), gpu_device)
     nat.attn_paged(q.to(gpu_device), H * D, kpool, vpool, bt.to(gpu_device), torch.tensor(lens, dtype=torch.int32).to(gpu_device),
                    torch.arange(B + 1, dtype=torch.int32, device=gpu_device), out, B, H, Hkv, D, 1, max(lens), D ** -0.5,
                    ns, ws)
     _close(out.view(B, H, D), want, rtol=2e-3, atol=2e-3, what="long decode attention")
+
+
+@pytest.mark.parametrize("dtype,B,H,Hkv,D,ctx", [
+    (torch.bfloat16, 16, 32, 4, 64, 512),    # cfg2: GQA 8:1, four key splits
+    (torch.float16, 4, 32, 32, 128, 700),    # MHA: four (sequence, head) groups share a 128-byte line of {m, l}
+    (torch.float16, 2, 48, 1, 128, 1500),    # MQA: three 16-head chunks per block
+])
+def test_split_decode_attention_merges_in_one_launch_every_time(nat, gpu_device, dtype, B, H, Hkv, D, ctx):
+    """Key-split decode attention merges its partial results inside the launch (the last block of each group to arrive
+    reads the others' records).  A stale read there — a line of another block's record served from this XCD's L2 or
+    L1 — would show as a result that changes between launches that re-use the same workspace, so: 200 launches
+    alternating two different q, each compared BIT for bit with the first result for that q, and the first results
+    against the un-split launch."""
+    g = torch.Generator().manual_seed(B + H + ctx)
+    lens = [ctx - 7 * i for i in range(B)]
+    pages_per = [(l + 31) // 32 for l in lens]
+    total_pages = sum(pages_per)
+    bt = torch.zeros((B, max(pages_per)), dtype=torch.int32)
+    perm = torch.randperm(total_pages, generator=g)
+    o = 0
+    for b in range(B):
+        bt[b, :pages_per[b]] = perm[o:o + pages_per[b]].int()
+        o += pages_per[b]
+    T = sum(lens)
+    dummy = torch.zeros((T, (H + 2 * Hkv) * D), dtype=dtype)
+    dummy[:, H * D:] = torch.randn(T, 2 * Hkv * D, generator=g).to(dtype)
+    slots = torch.cat([bt[b, torch.arange(l) // 32].long() * 32 + torch.arange(l) % 32 for b, l in enumerate(lens)]).int()
+    kpool = torch.zeros((total_pages, Hkv, 32 * D), dtype=dtype, device=gpu_device)
+    vpool = torch.zeros_like(kpool)
+    nat.rope_kv_write(dummy.to(gpu_device), None, None, None, slots.to(gpu_device), kpool, vpool, H, Hkv, D, D)
+    qs = [torch.randn(B, H * D, generator=g).to(dtype).to(gpu_device) for _ in range(2)]
+    ns = max(2, nat.attn_num_splits(B, Hkv, H, 1, max(lens)))
+    ws = nat.Workspace(nat.attn_workspace_bytes(B, H, Hkv, D, ns), gpu_device)
+    btd, ctxd = bt.to(gpu_device), torch.tensor(lens, dtype=torch.int32).to(gpu_device)
+    cuq = torch.arange(B + 1, dtype=torch.int32, device=gpu_device)
+
+    def run(q, splits):
+        out = torch.empty((B, H * D), dtype=dtype, device=gpu_device)
+        nat.attn_paged(q, H * D, kpool, vpool, btd, ctxd, cuq, out, B, H, Hkv, D, 1, max(lens), D ** -0.5, splits,
+                       ws if splits > 1 else None)
+        return out
+
+    first = [run(q, ns) for q in qs]
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    for q, f in zip(qs, first):
+        _close(f, run(q, 1).float().cpu(), rtol=tol, atol=tol, what=f"{ns} key splits against one")
+    for i in range(200):
+        assert torch.equal(run(qs[i & 1], ns), first[i & 1]), f"launch {i}: the merged result changed"
 
 
 # ---- elementwise / sampling ---------------------------------------------------------------------------------------
@@ -341,6 +389,32 @@ def test_gptq_partial_then_rope_kv_is_bit_identical_to_unfused(nat, gpu_device):
     q1 = nat.rope_kv_write(part, cos, sin, pos, slots, pools[2], pools[3], H, Hkv, D, D)
     assert torch.equal(q0, q1) and torch.equal(pools[0], pools[2]) and torch.equal(pools[1], pools[3])
     assert pools[0].abs().sum() > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,I", [(16, 2048, 5632), (32, 4096, 11008), (3, 256, 48), (40, 512, 1376), (64, 2048, 5632)])
+def test_dense_gemm_gate_up_epilogue(nat, gpu_device, dtype, M, K, I):
+    """Dense act=2: [gate | up] projection with SiLU(gate)*up in the epilogue (pairs interleaved at prepare time) against
+    the fp32 reference with the reference's rounding points, and against the un-fused pair of launches (plain GEMM, then
+    the down projection's act=1 staging of the same values), which may differ only by the summation order."""
+    g = torch.Generator().manual_seed(M + K + I)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(dtype)
+    w = (torch.randn(2 * I, K, generator=g) * 0.03).to(dtype)
+    bias = (torch.randn(2 * I, generator=g) * 0.05).to(dtype)
+    fused = nat.DenseWeight(w.to(gpu_device), gate_up=True)
+    ws = nat.Workspace(fused.workspace_bytes(M), gpu_device)
+    got = nat.dense_gemm(x.to(gpu_device), fused, ws, bias=bias.to(gpu_device), act=2)
+    assert got.shape == (M, I) and got.dtype == dtype
+    lin = (x.float() @ w.float().t() + bias.float()).to(dtype)
+    want = torch.nn.functional.silu(lin[:, :I].float()).to(dtype).float() * lin[:, I:].float()
+    eps = 2.0 ** -11 if dtype == torch.float16 else 2.0 ** -8
+    _close(got, want, rtol=8 * eps, atol=3 * eps * float(lin.float().abs().max()) + 1e-4, what="dense gate_up epilogue")
+    plain = nat.DenseWeight(w.to(gpu_device))
+    ws.ensure(plain.workspace_bytes(M))
+    unfused = nat.act_mul(nat.dense_gemm(x.to(gpu_device), plain, ws, bias=bias.to(gpu_device)), I)
+    diff = (got.float() - unfused.float()).abs()
+    assert float((diff > 0).float().mean()) < 0.02, "more than summation-order noise between fused and un-fused"
+    assert float(diff.max()) <= 4 * eps * float(lin.float().abs().max()) ** 2 + 1e-3
 
 
 @pytest.mark.parametrize("M,K,I", [(32, 4096, 11008), (3, 256, 48), (40, 512, 1376)])

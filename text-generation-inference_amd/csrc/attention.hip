@@ -162,6 +162,9 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
         }
     }
     __syncthreads();
+    const int grp = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * b);  // the NS blocks that share their columns
+    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.ws_o, 0, 0x7FFFFFFF, 0x00020000);
+    __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.ws_ml, 0, 0x7FFFFFFF, 0x00020000);
     // thread -> (chunk, column j, 8 consecutive d)
     for (int item = tid; item < CH * 16 * (D / 8); item += 64 * NW) {
         const int j = item & 15, dc = (item >> 4) % (D / 8), ch = item / (16 * (D / 8));
@@ -192,6 +195,17 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(acc[e] * inv);
             st16(reinterpret_cast<T*>(a.out) + (tokidx * a.H + headj) * D + dc * 8, ov);
+        } else if (a.counters) {
+            // fused combine: the record leaves as 16-byte write-through stores (no other block's record shares a
+            // 128-byte line with it: 16 columns x NS x 16 bytes per (group, chunk))
+            const int64_t rec = (((int64_t)grp * CH + ch) * 16 + j) * a.NS + split;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{acc[0], acc[1], acc[2], acc[3]}), ro,
+                                                   (uint32_t)((rec * D + dc * 8) * 4), 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{acc[4], acc[5], acc[6], acc[7]}), ro,
+                                                   (uint32_t)((rec * D + dc * 8 + 4) * 4), 0, 16);
+            if (dc == 0)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{mstar, l, 0.f, 0.f}), rm,
+                                                       (uint32_t)(rec * 16), 0, 16);
         } else {
             float* wo = a.ws_o + ((tokidx * a.H + headj) * a.NS + split) * D + dc * 8;
             *reinterpret_cast<f32x4*>(wo) = f32x4{acc[0], acc[1], acc[2], acc[3]};
@@ -202,6 +216,54 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
                 wm[1] = l;
             }
         }
+    }
+    if (a.NS == 1 || !a.counters) return;
+
+    // ---- the last of the group's NS blocks to get here merges the NS records (what attn_combine_kernel does in a
+    //      second launch otherwise).  Protocol of MI355X_MICROARCH.md: write-through (sc1) payload, drained, then an
+    //      agent-scope counter; the reader uses sc1 loads on lines its XCD cannot hold yet. ------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* lastp = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.counters + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old + 1u == (unsigned)a.NS;
+        if (last) __hip_atomic_store(a.counters + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+        *lastp = last;
+    }
+    __syncthreads();
+    if (!*lastp) return;
+    for (int item = tid; item < CH * 16 * (D / 8); item += 64 * NW) {
+        const int j = item & 15, dc = (item >> 4) % (D / 8), ch = item / (16 * (D / 8));
+        const int hc = hc0 + ch;
+        const int tqj = j / a.Gp, gj = j % a.Gp;
+        if (!(gj < a.Gc && hc * 16 + gj < a.G && t0 + tqj < q_len)) continue;
+        const int64_t rec0 = (((int64_t)grp * CH + ch) * 16 + j) * a.NS;
+        float mstar = NEG_BIG;
+        for (int s2 = 0; s2 < a.NS; ++s2) {
+            const f32x4 ml = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, (uint32_t)((rec0 + s2) * 16), 0, 16));
+            mstar = fmaxf(mstar, ml[0]);
+        }
+        float l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s2 = 0; s2 < a.NS; ++s2) {
+            const f32x4 ml = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, (uint32_t)((rec0 + s2) * 16), 0, 16));
+            const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, (uint32_t)(((rec0 + s2) * D + dc * 8) * 4), 0, 16));
+            const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, (uint32_t)(((rec0 + s2) * D + dc * 8 + 4) * 4), 0, 16));
+            const float f = exp2f(ml[0] - mstar);
+            l += ml[1] * f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[e] += lo[e] * f;
+                acc[e + 4] += hi[e] * f;
+            }
+        }
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        V8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(acc[e] * inv);
+        const int64_t tokidx = q0 + t0 + tqj;
+        const int headj = hk * a.G + hc * 16 + gj;
+        st16(reinterpret_cast<T*>(a.out) + (tokidx * a.H + headj) * D + dc * 8, ov);
     }
 }
 
@@ -246,25 +308,34 @@ static AttnGeom geom(int H, int Hkv) {
     return g;
 }
 
+// Decode with fewer than 256 (sequence, kv head) groups: blocks of 8 waves that share one group's keys page by page
+// (and merge through LDS) instead of more key splits merged across blocks.
+static bool wide_decode_blocks(int64_t groups, int ch) { return ch == 1 && groups < 256; }
+
 // 16-head chunks one decode block serves (register budget: 3 sets of O accumulators at D = 128)
 static int chunks_per_block(int HC, int64_t max_q_len) { return (max_q_len == 1 && HC > 1) ? std::min(HC, 3) : 1; }
 
+template <typename T, int D, int NW, int CH>
+static void launch_attn_one(const AttnArgs& a, dim3 grid, hipStream_t st) {
+    const size_t lds = (size_t)CH * (NW * D * 16 + NW * 2 * 16) * sizeof(float);
+    static bool attr = false;  // e.g. CH = 3, D = 128, NW = 4: 98 KB of combine scratch
+    if (!attr && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void*)attn_paged_kernel<T, D, NW, CH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((attn_paged_kernel<T, D, NW, CH>), grid, dim3(64 * NW), lds, st, a);
+}
+
 template <typename T, int D, int CH>
 static void launch_attn_nw(const AttnArgs& a, dim3 grid, hipStream_t st, int nw) {
-    const size_t lds = (size_t)CH * (nw * D * 16 + nw * 2 * 16) * sizeof(float);
-    if (nw == 1) {
-        hipLaunchKernelGGL((attn_paged_kernel<T, D, 1, CH>), grid, dim3(64), lds, st, a);
-    } else if (nw == 2) {
-        hipLaunchKernelGGL((attn_paged_kernel<T, D, 2, CH>), grid, dim3(128), lds, st, a);
-    } else {
-        static bool attr = false;  // CH = 3, D = 128: 98 KB of combine scratch
-        if (!attr && lds > 48 * 1024) {
-            (void)hipFuncSetAttribute((const void*)attn_paged_kernel<T, D, 4, CH>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
-        hipLaunchKernelGGL((attn_paged_kernel<T, D, 4, CH>), grid, dim3(256), lds, st, a);
+    if (nw == 1) return launch_attn_one<T, D, 1, CH>(a, grid, st);
+    if (nw == 2) return launch_attn_one<T, D, 2, CH>(a, grid, st);
+    if constexpr (CH == 1) {  // wide blocks: few (sequence, kv head) groups, the waves of one block share the keys
+        if (nw == 8) return launch_attn_one<T, D, 8, CH>(a, grid, st);
+        if (nw == 16) return launch_attn_one<T, D, 16, CH>(a, grid, st);
     }
+    launch_attn_one<T, D, 4, CH>(a, grid, st);
 }
 
 template <typename T, int D>
@@ -276,7 +347,7 @@ static int launch_attn(const AttnArgs& a, dim3 grid, int64_t total_q, hipStream_
     else
         launch_attn_nw<T, D, 1>(a, grid, st, nw);
     TGIS_CHECK_LAUNCH();
-    if (a.NS > 1) {
+    if (a.NS > 1 && !a.counters) {
         hipLaunchKernelGGL((attn_combine_kernel<T, D>), dim3((unsigned)(total_q * a.H)), dim3(64), 0, st, a.ws_o,
                            a.ws_ml, (T*)a.out, a.NS);
         TGIS_CHECK_LAUNCH();
@@ -297,16 +368,66 @@ extern "C" int tgis_attn_num_splits(int64_t B, int Hkv, int H, int64_t max_q_len
     // (tools/split_sweep.py: B=32 MQA ctx 4096: 19 us at 8 splits vs 26 us at 32)
     // (multi-chunk blocks hold three sets of accumulators: one block per CU, so one round of 256 —
     //  tools/attn_mqa.py, 48 q heads on 1 kv head, B=32 ctx 4096: 26.7 us at 8 splits, 38 at 16, 32 at 4)
-    int64_t ns = cdiv64(ch > 1 ? 256 : 512, base);
-    ns = std::min<int64_t>(ns, cdiv64(pages, 4));  // at least one page per wave
+    int64_t ns;
+    if (wide_decode_blocks(base, ch)) {
+        // few (sequence, kv head) groups: 8-wave blocks, one round of <= 256 of them, >= 2 pages per wave
+        // (tools/attn_nw.py, us: B=16 GQA 8:1 D=64 ctx 512: 6.8 unsplit vs 8.5 at 4 splits of 4 waves;
+        //  B=1 MHA D=128 ctx 2048: 14.1 at 8 splits vs 17.7 at 16; B=4 GQA 4:1 ctx 4096: 19.0 at 8 vs 24.0 at 16)
+        ns = std::min<int64_t>(cdiv64(256, base), pages / 16);
+    } else {
+        ns = cdiv64(ch > 1 ? 256 : 512, base);
+        ns = std::min<int64_t>(ns, cdiv64(pages, 4));  // at least one page per wave
+    }
     ns = std::max<int64_t>(1, std::min<int64_t>(ns, 64));
     return (int)ns;
 }
 
-extern "C" int64_t tgis_attn_workspace_bytes(int64_t total_q_tokens, int H, int D, int num_splits) {
-    if (num_splits <= 1) return 0;
-    return total_q_tokens * H * num_splits * ((int64_t)D + 2) * 4;
+// records of the fused combine: [group = (sequence, kv head, chunk block)][chunk][16 columns][split]
+static int64_t fused_records(int64_t B, int H, int Hkv, int num_splits) {
+    AttnGeom g = geom(H, Hkv);
+    const int ch = chunks_per_block(g.HC, 1);
+    return B * Hkv * cdiv64(g.HC, ch) * ch * 16 * num_splits;
 }
+
+extern "C" int64_t tgis_attn_workspace_bytes(int64_t total_q_tokens, int H, int Hkv, int D, int num_splits) {
+    if (num_splits <= 1 || Hkv <= 0 || H % Hkv != 0) return 0;
+    // the larger of the two layouts: per (token, head, split) {O[D], m, l} for the two-launch combine, or the
+    // line-padded records of the fused one (16 columns per group and chunk, {m, l} in 16 bytes)
+    const int64_t two_pass = total_q_tokens * H * num_splits * ((int64_t)D + 2) * 4;
+    const int64_t fused = fused_records(total_q_tokens, H, Hkv, num_splits) * ((int64_t)D + 4) * 4;
+    return std::max(two_pass, fused);
+}
+
+namespace {
+constexpr int64_t ATTN_COUNTERS = 1 << 20;
+unsigned* g_attn_counters[16] = {};
+
+// Arrival counters of the fused combine, one per group; zero between launches (the last arriver resets its own).
+// Owned by the library, one array per device: launches that may overlap on one device (several streams) must not
+// both use key splits.  Never allocated while the stream is capturing (the first, un-captured call does it).
+unsigned* attn_counters(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!g_attn_counters[dev]) {
+        static const bool off = getenv("TGIS_ATTN_FUSED_COMBINE") && atoi(getenv("TGIS_ATTN_FUSED_COMBINE")) == 0;
+        if (off) return nullptr;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        unsigned* p = nullptr;
+        if (hipMalloc((void**)&p, ATTN_COUNTERS * sizeof(unsigned)) != hipSuccess ||
+            hipMemset(p, 0, ATTN_COUNTERS * sizeof(unsigned)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        (void)hipDeviceSynchronize();
+        g_attn_counters[dev] = p;
+    }
+    return g_attn_counters[dev];
+}
+}  // namespace
 
 extern "C" int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, const void* v_pool,
                                const int32_t* block_tables, int64_t max_pages, const int32_t* ctx_lens,
@@ -348,15 +469,23 @@ extern "C" int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, 
     a.scale_log2 = scale * 1.4426950408889634f;
     a.ws_o = nullptr;
     a.ws_ml = nullptr;
+    a.counters = nullptr;
     int64_t total_q = 0;
     if (num_splits > 1) {
         // total q tokens is only needed to size the split workspace; callers pass B*max_q_len rows
         total_q = B * max_q_len;
-        int64_t need = tgis_attn_workspace_bytes(total_q, H, D, num_splits);
+        int64_t need = tgis_attn_workspace_bytes(total_q, H, Hkv, D, num_splits);
         TGIS_CHECK_ARG(workspace && workspace_bytes >= need, "tgis_attn_paged: workspace too small (%ld < %ld)",
                        (long)workspace_bytes, (long)need);
         a.ws_o = (float*)workspace;
         a.ws_ml = a.ws_o + total_q * H * num_splits * D;
+        // one launch: the last block of each (sequence, kv head) group merges the splits (no combine launch)
+        const int64_t recs = fused_records(B, H, Hkv, num_splits);
+        const int64_t groups = B * Hkv * a.HCB;
+        if (groups <= ATTN_COUNTERS && recs * D * 4 < (1ll << 31)) {
+            a.counters = attn_counters(st);
+            if (a.counters) a.ws_ml = a.ws_o + recs * D;
+        }
     }
     // long q (prefill): blocks of 128 columns that stage each K/V page once in LDS (attention_prefill.hip)
     if (num_splits == 1 && max_q_len * g.Gp > 64 && !getenv("TGIS_ATTN_NO_PREFILL_KERNEL")) {
@@ -372,7 +501,12 @@ extern "C" int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, 
     const int64_t nblocks = (int64_t)grid.x * grid.y * grid.z;
     // (past ~2k blocks the dispatch rate, 7 ns per workgroup, costs more than the imbalance)
     int nw = (max_q_len == 1 && nblocks >= 1024 && nblocks < 2048) ? 2 : 4;
-    if (const char* e = getenv("TGIS_ATTN_NW")) nw = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 4;
+    if (max_q_len == 1 && wide_decode_blocks(nblocks / num_splits, ch)) nw = 8;
+    if (const char* e = getenv("TGIS_ATTN_NW")) {
+        const int v = atoi(e);
+        nw = (v == 1 || v == 2 || v == 8 || v == 16) ? v : 4;
+        if (ch > 1 && nw > 4) nw = 4;
+    }
     TgisTimedScope timed(TGIS_OP_ATTN, st);
     if (dtype == TGIS_F16) {
         if (D == 128) return launch_attn<f16, 128>(a, grid, total_q, st, nw, ch);

@@ -15,8 +15,9 @@ struct AttnArgs {
     int H, Hkv, G, Gc, Gp, TQ, HC, NS;
     int HCB;  // decode kernel: blocks per kv head along the 16-head chunks (HC / chunks per block)
     float scale_log2;
-    float* ws_o;   // [total_q][H][NS][D]
-    float* ws_ml;  // [total_q][H][NS][2]
+    float* ws_o;   // [total_q][H][NS][D]        (fused combine: [group][chunk][16 columns][NS][D])
+    float* ws_ml;  // [total_q][H][NS][2]        (fused combine: [group][chunk][16 columns][NS][4], {m, l, -, -})
+    unsigned* counters;  // fused combine: per-group arrival counters (zero between launches), or nullptr
 };
 
 constexpr float NEG_BIG = -1.0e30f;

@@ -8,12 +8,15 @@
 #include <algorithm>
 #include <type_traits>
 #include "common.h"
+#include "dense_gemm_body.h"
 
 namespace {
 
+// gate_up: W is [gate rows | up rows] (N = 2 I); tile nt then holds gate rows 16 nt .. +15 in columns 0..15 and the
+// matching up rows in columns 16..31, so that the ACT = 2 epilogue finds each (gate, up) pair inside one wave.
 template <typename T>
 __global__ void dense_prepare_kernel(const T* __restrict__ w, T* __restrict__ out, int64_t N, int64_t K,
-                                     int64_t NT, int64_t KS) {
+                                     int64_t NT, int64_t KS, int gate_up) {
     using V8 = typename VecT<T>::x8;
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk each
     if (idx >= NT * KS * 256) return;
@@ -22,6 +25,10 @@ __global__ void dense_prepare_kernel(const T* __restrict__ w, T* __restrict__ ou
     int64_t ks = (idx >> 8) % KS;
     int64_t nt = (idx >> 8) / KS;
     int64_t n = nt * 32 + (l & 31);
+    if (gate_up) {
+        const int64_t half = N >> 1, j = nt * 16 + (l & 15);
+        n = j < half ? ((l & 31) < 16 ? j : half + j) : N;  // past the last pair: a zero column
+    }
     int64_t k = (ks * 8 + (l >> 5) * 4 + i) * 8;
     V8 v;
 #pragma unroll
@@ -37,235 +44,20 @@ __global__ void dense_prepare_kernel(const T* __restrict__ w, T* __restrict__ ou
     st16(out + idx * 8, v);
 }
 
-struct DenseArgs {
-    const void* x;
-    int64_t ldx;
-    const uint8_t* prep;
-    const void* bias;
-    void* out;
-    int64_t ldo;
-    int M, K, N;   // M = all rows (grid.z walks 32-row slabs)
-    int KR;        // k-range per block (multiple of 256 * WK)
-    int S;         // global k splits
-    int NT, KS;
-    int out_f32;
-    float* slabs;  // [Mslabs][S][32][NT*32] f32 partial sums (S > 1 or partial mode)
-    int partial;   // 1: always leave fp32 slabs (deferred reduce), never write `out`
-};
+using dense::DenseArgs;
+using dense::DensePlan;
+using dense::DRS;
+using dense::plan_dense;
+using dense::dense_slab_bytes;
 
-constexpr int DKC = 256;      // k per LDS chunk (4 k64-steps)
-constexpr int DRS = DKC + 8;  // LDS row stride in elements (+16 B -> conflict-free ds_read_b128)
-constexpr int DRING = 2;      // k64-steps of weights in flight per wave (2 x 4 KiB)
-#define DENSE_GLOBAL_AS __attribute__((address_space(1)))
-
-// Same structure as gptq_gemm_kernel (gptq.hip) without the dequantisation: a block of TN*WK waves owns 32*TN columns
-// x KR rows; wave (tile wn, k-part wk) streams its tile's fragments over its own k-range (4 KiB per k64-step, two
-// steps in flight, refilled in place), each k-part group double-buffers 32x256 chunks of x through LDS and paces
-// itself with an LDS arrival counter; k-parts are summed through LDS in fixed order; global k-splits leave fp32
-// slabs for the consumer kernel.  The image is zero-padded past K and N; x columns past the wave's k-range are
-// zeroed when the chunk is staged (the fragments there belong to the next k-part).
-// MR = 32-row blocks of x per pass (2 for M > 32: every weight fragment then feeds two MFMAs instead of being streamed
-// again for rows 32..63; needs WK = 2 for the doubled x buffers).
+// One workgroup = one unit of dense_gemm_body.h (block-wide barriers, plain loads and stores).
 template <typename T, int TN, int WK, int ACT, int MR>
 __global__ __launch_bounds__(64 * TN * WK) void dense_gemm_kernel(DenseArgs a) {
-    static_assert(MR == 1 || WK == 2, "64-row passes need the LDS of two k-parts");
-    using V8 = typename VecT<T>::x8;
-    constexpr int XR = 32 * MR;
-    constexpr int GT = 64 * TN;
-    constexpr int NJ = (XR * 32 + GT - 1) / GT;
-    constexpr int RSTEP = GT / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = w % TN, wk = w / TN, ltid = wn * 64 + lane;
-    T* xs = reinterpret_cast<T*>(smem) + wk * (2 * XR * DRS);
-    const int ntg = blockIdx.x, split = blockIdx.y, mslab = blockIdx.z;
-    const int m0 = mslab * XR;
-    const int mrows = min(XR, a.M - m0);
-    const int krp = a.KR / WK;
-    const int k0 = split * a.KR + wk * krp;
-    const int k1 = min(a.K, k0 + krp);
-    const int nchunks = krp / DKC;
-    const int nt_raw = ntg * TN + wn;
-    const int nt = min(nt_raw, a.NT - 1);
-    const int ks0 = k0 >> 6;
-    const int ks_clamp = min(a.KS - 1, max(ks0, ((k1 + 63) >> 6) - 1));
-
-    const char* wtile = reinterpret_cast<const char*>(a.prep) + (int64_t)nt * a.KS * 4096;
-    const uint32_t woff = lane * 16;
-    V8 wq[DRING][4];
-    auto w_load = [&](int step, V8* dst) {
-        const char* p = wtile + (int64_t)min(ks0 + step, ks_clamp) * 4096;
-        asm volatile("" : "+s"(p));  // wave-uniform base in SGPRs: (sgpr base + lane offset) addressing
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            dst[i] = __builtin_nontemporal_load((const DENSE_GLOBAL_AS V8*)(p + i * 1024 + woff));
-    };
-
-    // ---- x staging (as in gptq.hip): rows past M read a clamped row (their outputs are never stored); columns past
-    //      the k-range are zeroed at store time --------------------------------------------------------------------
-    const T* xbase = reinterpret_cast<const T*>(a.x) + (int64_t)m0 * a.ldx;
-    const int srow = ltid >> 5, scol = (ltid & 31) * 8;
-    V8 xg[NJ], xu[NJ];
-    bool xok;
-    uint32_t rowoff[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) rowoff[j] = (uint32_t)(min(srow + RSTEP * j, mrows - 1) * (int)a.ldx * 2);
-    auto stage_load = [&](int chunk) {
-        const int kk = k0 + chunk * DKC + scol;
-        xok = kk < k1;
-        const int kc = min(kk, a.K - 8);
-        const char* xb = reinterpret_cast<const char*>(xbase);
-        asm volatile("" : "+s"(xb));
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const uint32_t off = rowoff[j] + (uint32_t)kc * 2;
-            xg[j] = *(const DENSE_GLOBAL_AS V8*)(xb + off);
-            if (ACT == 1) xu[j] = *(const DENSE_GLOBAL_AS V8*)(xb + (int64_t)a.K * 2 + off);
-        }
-    };
-    auto stage_store = [&](int buf) {
-        T* dst = xs + buf * (XR * DRS) + srow * DRS + scol;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            V8 t = xg[j];
-            if (ACT == 1) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float g = to_f32(t[e]);
-                    float sl = g / (1.f + __expf(-g));
-                    // reference rounds silu(gate) to the model dtype before the multiply (eager torch ops)
-                    t[e] = from_f32<T>(to_f32(from_f32<T>(sl)) * to_f32(xu[j][e]));
-                }
-            }
-            if (!xok) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] = (T)0.f;
-            }
-            if (NJ * RSTEP == XR || srow + RSTEP * j < XR) st16(dst + j * RSTEP * DRS, t);
-        }
-    };
-
-    f32x16 accs[MR][2];
-#pragma unroll
-    for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) accs[mr][i] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int xoff = (lane & 31) * DRS + (lane >> 5) * 32;
-
-    typedef __attribute__((address_space(3))) int lds_int;
-    volatile lds_int* sync_cnt = (volatile lds_int*)(smem + (size_t)WK * 2 * XR * DRS * sizeof(T)) + wk;
-    if (wn == 0 && lane == 0) *sync_cnt = 0;
-    stage_load(0);  // x first: a wave's loads return in order and this one is L2-resident
-#pragma unroll
-    for (int s = 0; s < DRING; ++s) w_load(s, wq[s]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // publishes the zeroed counters; does not wait for the loads above
-    auto group_sync = [&](int target) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add((lds_int*)sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__builtin_amdgcn_readfirstlane(*sync_cnt) < target) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-    };
-    stage_store(0);
-    group_sync(TN);
-
-    auto chunk_body = [&](const int chunk, auto last_tag) {
-        constexpr bool LAST = decltype(last_tag)::value;
-        if (!LAST) stage_load(chunk + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const T* xbuf = xs + (chunk & 1) * (XR * DRS) + xoff;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const int step = chunk * 4 + s4;
-            const T* xk = xbuf + s4 * 64;
-            V8* cur = wq[s4 & (DRING - 1)];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int mr = 0; mr < MR; ++mr) {
-                    V8 av = ld16<V8>(xk + mr * (32 * DRS) + i * 8);
-                    accs[mr][i & 1] = mfma32(av, cur[i], accs[mr][i & 1]);
-                }
-            // the slot is consumed: refill it in place, DRING steps ahead (the last chunk only refills what it
-            // will still consume itself)
-            if (!LAST || s4 + DRING < 4) {
-                __builtin_amdgcn_sched_barrier(0);
-                w_load(step + DRING, cur);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (LAST) return;
-        stage_store((chunk + 1) & 1);
-        group_sync(TN * (chunk + 2));
-    };
-    for (int chunk = 0; chunk + 1 < nchunks; ++chunk) chunk_body(chunk, std::false_type{});
-    chunk_body(nchunks - 1, std::true_type{});
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every k-part is done with its x buffers: the reduction below reuses them
-
-    f32x16 acc[MR];
-#pragma unroll
-    for (int mr = 0; mr < MR; ++mr) acc[mr] = accs[mr][0] + accs[mr][1];
-    if (WK > 1) {
-        float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][MR][64 lanes][16]
-        if (wk > 0) {
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr) {
-                float* dst = red + ((((wk * TN + wn) * MR + mr) * 64 + lane) << 4);
-#pragma unroll
-                for (int r = 0; r < 16; r += 4)
-                    *reinterpret_cast<f32x4*>(dst + r) = f32x4{acc[mr][r], acc[mr][r + 1], acc[mr][r + 2], acc[mr][r + 3]};
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (wk > 0) return;
-#pragma unroll
-        for (int k2 = 1; k2 < WK; ++k2)
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr) {
-                const float* src = red + ((((k2 * TN + wn) * MR + mr) * 64 + lane) << 4);
-#pragma unroll
-                for (int r = 0; r < 16; r += 4) {
-                    f32x4 t = *reinterpret_cast<const f32x4*>(src + r);
-                    acc[mr][r] += t[0];
-                    acc[mr][r + 1] += t[1];
-                    acc[mr][r + 2] += t[2];
-                    acc[mr][r + 3] += t[3];
-                }
-            }
-    }
-
-    // ---- epilogue: lane holds out[m = 32 mr + (r&3)+8(r>>2)+4(lane>>5)][n = nt*32 + (lane&31)] -------
-    if (nt_raw >= a.NT) return;
-    const int n = nt * 32 + (lane & 31);
-    if (a.S == 1 && !a.partial) {
-        if (n >= a.N) return;
-        const float bv = a.bias ? to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= mrows) continue;
-                if (a.out_f32)
-                    reinterpret_cast<float*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = acc[mr][r] + bv;
-                else
-                    reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = from_f32<T>(acc[mr][r] + bv);
-            }
-    } else {
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr) {
-            float* sl = a.slabs + ((int64_t)((mslab * MR + mr) * a.S + split) * 32) * (a.NT * 32) + n;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                sl[(int64_t)m * (a.NT * 32)] = acc[mr][r];
-            }
-        }
-    }
+    dense::DenseRing<T> ring;
+    dense::dense_gemm_unit<T, TN, WK, ACT, MR, false, dense::UNIT_FULL>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem, 0, ring);
 }
+
 
 // Sum the S split-K slabs in fixed order and emit the output (+bias); thread = (row, 4 columns).
 template <typename T>
@@ -293,82 +85,6 @@ __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float* _
     }
 }
 
-struct DensePlan {
-    int KR, S, WK, TN, MR;
-};
-
-// Same shape rules as plan_gemm (gptq.hip) — the bytes per tile are 4x, the block structure is the same.
-static DensePlan plan_dense(int64_t K, int64_t N, int64_t M = 32) {
-    const int64_t tiles = cdiv64(N, 32);
-    const int64_t kchunks = cdiv64(K, DKC);
-    const int MR = M > 32 ? 2 : 1;
-    int TN, WK;
-    int64_t S = 1;
-    if (MR == 2) {
-        TN = tiles >= 256 ? 4 : 2;
-        WK = 2;
-        const int64_t colblocks = cdiv64(tiles, TN) * cdiv64(M, 64);
-        S = std::max<int64_t>(1, std::min<int64_t>(kchunks / 2, (224 + colblocks / 2) / colblocks));
-        while (S > 1 && (S - 1) * cdiv64(kchunks, S) >= kchunks) --S;
-    } else if (tiles >= 512) {
-        TN = cdiv64(tiles, 3) <= 256 ? 3 : 4;
-        WK = 4;
-    } else if (K * N * 2 < (48ll << 20)) {
-        // small matrices are latency-bound: as many blocks as one round holds, short k-parts (TinyLlama sweeps)
-        TN = tiles >= 256 ? 4 : 2;
-        const int64_t colblocks = cdiv64(tiles, TN);
-        const int64_t want = TN == 4 ? 224 : 256;
-        S = std::max<int64_t>(1, std::min<int64_t>(kchunks, (want + colblocks / 2) / colblocks));
-        while (S > 1 && (S - 1) * cdiv64(kchunks, S) >= kchunks) --S;  // no empty last split
-        WK = TN == 4 ? 2 : (cdiv64(kchunks, S) >= 4 ? 4 : 2);
-    } else {
-        // Narrow / medium N, bandwidth-bound sizes: pick (TN, WK, S) by a two-term model of a launch — a dense block streams
-        // KR x 32 TN x 2 bytes; blocks run in rounds of one per CU (two for the half-size LDS of WK = 2); a round takes
-        // max(block bytes / per-CU rate, round bytes / chip rate) + a fixed ramp; each extra split adds slab traffic.
-        // The rates are the ones measured on MI355X (one block alone ~50 GB/s, the chip 5.9 TB/s for this access
-        // pattern).  It reproduces the measured 72 us of 24576x6144 at (2,4,S=3: 288 blocks = two rounds) and picks
-        // (3,4,S=4: 256 blocks, one round) instead.
-        double best = 1e30;
-        TN = 2, WK = 4, S = 1;
-        for (int tn = 2; tn <= 4; ++tn)
-            for (int wk = 4; wk >= 2; wk -= 2) {
-                if (tn == 3 && wk == 2) continue;  // not instantiated
-                for (int64_t sp = 1; sp <= std::min<int64_t>(16, kchunks); ++sp) {
-                    int64_t krc = cdiv64(cdiv64(kchunks, sp), wk) * wk;
-                    if (sp > 1 && (sp - 1) * krc >= kchunks) continue;  // an empty last split
-                    const int64_t blocks = cdiv64(tiles, tn) * sp;
-                    const double block_bytes = (double)krc * DKC * tn * 32 * 2;
-                    const int64_t slots = wk == 2 ? 512 : 256;
-                    const double cu_rate = wk == 2 ? 25.0 : 50.0;  // GB/s per block: two half-LDS blocks share a CU
-                    double ns = sp > 1 ? 500.0 * sp : 0.0;
-                    for (int64_t left = blocks; left > 0; left -= slots) {
-                        const int64_t n = std::min(left, slots);
-                        ns += std::max(block_bytes / cu_rate, n * block_bytes / 5900.0) + 4000.0;
-                    }
-                    if (ns < best - 1.0) {
-                        best = ns;
-                        TN = tn, WK = wk, S = sp;
-                    }
-                }
-            }
-        if (const char* ov = getenv("TGIS_DENSE_PLAN")) {  // tuning hook: "S,WK,TN"
-            int sp = 0, wk = 0, tn = 0;
-            if (sscanf(ov, "%d,%d,%d", &sp, &wk, &tn) == 3 && sp >= 1 && (wk == 2 || wk == 4) && tn >= 2 && tn <= 4 &&
-                !(tn == 3 && wk == 2))
-                TN = tn, WK = wk, S = sp;
-        }
-    }
-    int64_t KRc = cdiv64(kchunks, S);
-    if (KRc < WK) WK = 2;
-    KRc = cdiv64(KRc, WK) * WK;
-    while (S > 1 && (S - 1) * KRc >= kchunks) --S;
-    return {(int)(KRc * DKC), (int)S, WK, TN, MR};
-}
-
-// slabs are stored in 32-row units; a 64-row pass always writes both of its units
-static int64_t dense_slab_bytes(int64_t M, int64_t N, int S) {
-    return cdiv64(M, 64) * 2 * S * 32 * cdiv64(N, 32) * 32 * 4;
-}
 
 template <typename T, int TN, int WK, int ACT, int MR>
 static int launch_dense_one(dim3 grid, size_t lds, hipStream_t st, const DenseArgs& a) {
@@ -396,7 +112,9 @@ static int launch_dense(const DenseArgs& a, const DensePlan& pl, int act, int64_
     int rc = TGIS_EINVAL;
 #define TGIS_DENSE_CASE(T_, W_)                                                        \
     if (pl.TN == T_ && pl.WK == W_)                                                    \
-        rc = act ? launch_dense_variant<T, T_, W_, 1>(pl.MR, grid, lds, st, a) : launch_dense_variant<T, T_, W_, 0>(pl.MR, grid, lds, st, a)
+        rc = act == 2   ? launch_dense_variant<T, T_, W_, 2>(pl.MR, grid, lds, st, a)                                           \
+             : act == 1 ? launch_dense_variant<T, T_, W_, 1>(pl.MR, grid, lds, st, a)                                           \
+                        : launch_dense_variant<T, T_, W_, 0>(pl.MR, grid, lds, st, a)
     TGIS_DENSE_CASE(2, 2);
     TGIS_DENSE_CASE(2, 4);
     TGIS_DENSE_CASE(3, 4);
@@ -425,24 +143,27 @@ extern "C" int64_t tgis_dense_prepared_bytes(int64_t N, int64_t K) {
     return cdiv64(N, 32) * cdiv64(K, 64) * 4096;
 }
 
-extern "C" int tgis_dense_prepare(const void* w, int64_t N, int64_t K, int dtype, void* prepared, void* stream) {
+extern "C" int tgis_dense_prepare(const void* w, int64_t N, int64_t K, int dtype, int flags, void* prepared,
+                                  void* stream) {
     TGIS_CHECK_ARG(w && prepared && N > 0 && K > 0, "tgis_dense_prepare: bad arguments");
     TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "tgis_dense_prepare: bad dtype");
+    const int gate_up = flags & 1;
+    TGIS_CHECK_ARG(!gate_up || N % 32 == 0, "tgis_dense_prepare: the gate|up image needs N / 2 to be a multiple of 16");
     int64_t NT = cdiv64(N, 32), KS = cdiv64(K, 64);
     int64_t total = NT * KS * 256;
     dim3 grid((unsigned)cdiv64(total, 256));
     if (dtype == TGIS_F16)
         hipLaunchKernelGGL(dense_prepare_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)w,
-                           (f16*)prepared, N, K, NT, KS);
+                           (f16*)prepared, N, K, NT, KS, gate_up);
     else
         hipLaunchKernelGGL(dense_prepare_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)w,
-                           (bf16*)prepared, N, K, NT, KS);
+                           (bf16*)prepared, N, K, NT, KS, gate_up);
     TGIS_CHECK_LAUNCH();
     return TGIS_OK;
 }
 
 extern "C" int64_t tgis_dense_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N) {
-    DensePlan pl = plan_dense(K, N, M);
+    DensePlan pl = plan_dense(K, N, M);  // (act 2 never splits: this bound covers it)
     return 4096 + (pl.S > 1 ? dense_slab_bytes(M, N, pl.S) : 0);
 }
 
@@ -452,7 +173,8 @@ static int dense_check(const void* x, int64_t ldx, const void* prepared, int64_t
     TGIS_CHECK_ARG(M >= 0 && K > 0 && N > 0, "tgis_dense_gemm: bad shape");
     TGIS_CHECK_ARG(K % 8 == 0, "tgis_dense_gemm: K (%ld) must be a multiple of 8", (long)K);
     TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "tgis_dense_gemm: bad dtype");
-    TGIS_CHECK_ARG(act == 0 || act == 1, "tgis_dense_gemm: act must be 0 or 1");
+    TGIS_CHECK_ARG(act >= 0 && act <= 2, "tgis_dense_gemm: act must be 0, 1 or 2");
+    TGIS_CHECK_ARG(act != 2 || N % 32 == 0, "tgis_dense_gemm: act 2 needs a gate|up image (N / 2 a multiple of 16)");
     TGIS_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, "tgis_dense_gemm: x rows must be 16-byte aligned");
     return TGIS_OK;
 }
@@ -476,6 +198,7 @@ static void dense_fill(DenseArgs& a, const void* x, int64_t ldx, const void* pre
     a.out_f32 = out_f32;
     a.slabs = slabs;
     a.partial = partial;
+    a.err = nullptr;
 }
 
 extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared, const void* bias, void* out,
@@ -486,7 +209,8 @@ extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared,
     TGIS_CHECK_ARG(out, "tgis_dense_gemm: null out");
     if (M == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
-    DensePlan pl = plan_dense(K, N, M);
+    DensePlan pl = plan_dense(K, N, M, act);
+    TGIS_CHECK_ARG(act != 2 || (!out_f32 && pl.S == 1), "tgis_dense_gemm: act 2 writes the model dtype, unsplit");
     const int64_t need = tgis_dense_gemm_workspace_bytes(M, K, N);
     TGIS_CHECK_ARG(workspace && workspace_bytes >= need, "tgis_dense_gemm: workspace too small (%ld < %ld)",
                    (long)workspace_bytes, (long)need);
@@ -507,6 +231,7 @@ extern "C" int tgis_dense_gemm_partial(const void* x, int64_t ldx, const void* p
                                        int* num_slabs, int64_t* slab_ld, void* stream) {
     int rc = dense_check(x, ldx, prepared, M, K, N, dtype, act);
     if (rc != TGIS_OK) return rc;
+    TGIS_CHECK_ARG(act != 2, "tgis_dense_gemm_partial: the SiLU * up epilogue needs the finished sum (use tgis_dense_gemm)");
     TGIS_CHECK_ARG(M >= 1 && cdiv64(M, 32) <= 65535, "tgis_dense_gemm_partial: bad M");
     TGIS_CHECK_ARG(slabs && slabs_bytes >= tgis_dense_gemm_partial_bytes(M, K, N),
                    "tgis_dense_gemm_partial: slab buffer too small");

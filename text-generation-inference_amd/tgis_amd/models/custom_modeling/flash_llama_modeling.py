@@ -154,7 +154,7 @@ class FlashLlamaAttention:
         if kv.num_splits > 1:
             from tgis_amd.utils.layers import workspace
             ws = workspace(qkv.device)
-            ws.ensure(native.attn_workspace_bytes(T, H, D, kv.num_splits))
+            ws.ensure(native.attn_workspace_bytes(T, H, Hkv, D, kv.num_splits))
         native.attn_paged(qkv, qkv.stride(0), k_pool, v_pool, kv.block_tables, kv.ctx_lens, cu_seqlens_q,
                           attn_output, B, H, Hkv, D, kv.max_q_len, kv.max_ctx, self.softmax_scale, kv.num_splits, ws)
         return attn_output
@@ -241,19 +241,27 @@ class FlashLlamaModel:
         return self._tails
 
     def _build_decode_tails(self):
-        def gptq(lin):
+        def image(lin):
+            """(weight image, bias) of a linear the tail can run: an un-permuted int4 image or a dense one."""
             h = getattr(lin, "q_handle", None)
-            return None if h is None or h.perm is not None else (h, lin.bias)
+            if h is not None:
+                return None if h.perm is not None else (h, lin.bias)
+            d = getattr(lin, "prepared", None)
+            return (d, lin.bias) if isinstance(d, native.DenseWeight) else None
 
         tails = []
         for i, layer in enumerate(self.layers):
             nxt = self.layers[i + 1] if i + 1 < len(self.layers) else None
-            o, gu, down = (gptq(layer.self_attn.o_proj.linear), gptq(layer.mlp.gate_up_proj.linear),
-                           gptq(layer.mlp.down_proj.linear))
-            qkv = gptq(nxt.self_attn.query_key_value.linear) if nxt is not None else None
-            if None in (o, gu, down) or not layer.mlp.fused_epilogue or (nxt is not None and qkv is None):
+            o, gu, down = (image(layer.self_attn.o_proj.linear), image(layer.mlp.gate_up_proj.linear),
+                           image(layer.mlp.down_proj.linear))
+            qkv = image(nxt.self_attn.query_key_value.linear) if nxt is not None else None
+            if None in (o, gu, down) or (nxt is not None and qkv is None):
                 return False
-            if layer.input_layernorm.weight.dtype != torch.float16:
+            dense = isinstance(o[0], native.DenseWeight)
+            kinds = {isinstance(l[0], native.DenseWeight) for l in (o, gu, down, qkv) if l is not None}
+            if kinds != {dense} or (not dense and not layer.mlp.fused_epilogue):
+                return False
+            if not dense and layer.input_layernorm.weight.dtype != torch.float16:
                 return False
             if not native.decode_tail_fits(32, o[0], gu[0], down[0], qkv[0] if qkv is not None else None):
                 return False
@@ -293,7 +301,7 @@ class FlashLlamaModel:
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
         hidden_states = inputs_embeds if inputs_embeds is not None else self.embed_tokens(input_ids)
         cos, sin = self.rope_tables(hidden_states.dtype, hidden_states.device, max_s)
-        if kv.max_q_len == 1 and not kv.fresh_prefill and hidden_states.dtype == torch.float16:
+        if kv.max_q_len == 1 and not kv.fresh_prefill:
             tails = self._decode_tails(hidden_states.shape[0])
             if tails:
                 return self._forward_decode_tail(tails, hidden_states, cos, sin, position_ids, cu_seqlens_q, kv)

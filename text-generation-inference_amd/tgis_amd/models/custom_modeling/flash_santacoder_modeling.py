@@ -135,7 +135,7 @@ class FlashMQAttention:
         ws = None
         if kv.num_splits > 1:
             ws = workspace(qkv.device)
-            ws.ensure(native.attn_workspace_bytes(T, H, D, kv.num_splits))
+            ws.ensure(native.attn_workspace_bytes(T, H, 1, D, kv.num_splits))
         native.attn_paged(qkv, qkv.stride(0), k_pool, v_pool, kv.block_tables, kv.ctx_lens, cu_seqlens_q,
                           attn_output, kv.block_tables.shape[0], H, 1, D, kv.max_q_len, kv.max_ctx,
                           self.softmax_scale, kv.num_splits, ws)

@@ -30,7 +30,7 @@ from tgis_amd.models.custom_modeling.flash_llama_modeling import KVArgs
 from tgis_amd.models.model import Model
 from tgis_amd.models.types import Batch, GenerateError
 from tgis_amd.pb import generate_pb2
-from tgis_amd.utils.graph_segments import SegmentedGraph
+from tgis_amd.utils.graph_segments import SegmentedGraph, no_gc_during_capture
 from tgis_amd.utils.kv_cache import PAGE, PagedKVCache
 from tgis_amd.utils.token_types import InputTokens, TokenInfo
 from tgis_amd.utils.tokens import HeterogeneousNextTokenChooser, get_input_tokens_info, get_token_info
@@ -348,7 +348,7 @@ class _DecodeGraph:
                 kw = {"capture_error_mode": "thread_local"} if self.lm.tp_world > 1 else {}
                 ok = True
                 try:
-                    with torch.cuda.graph(g, pool=self.lm.graph_pool, **kw):
+                    with no_gc_during_capture(), torch.cuda.graph(g, pool=self.lm.graph_pool, **kw):
                         self.logits, self.ids, self.logprobs = self._step()
                 except Exception as exc:
                     if self.lm.tp_world == 1:
@@ -481,7 +481,7 @@ class FlashCausalLM(Model):
             torch.cuda.synchronize(self.device)
             t.fill_(1.0)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with no_gc_during_capture(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                 torch.distributed.all_reduce(t, group=pg)
             g.replay()
             g.replay()

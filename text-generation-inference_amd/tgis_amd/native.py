@@ -39,7 +39,7 @@ class TailArgs(ctypes.Structure):
                 ("norm1_weight", _vp), ("norm2_weight", _vp), ("y1", _vp), ("res1", _vp), ("act", _vp), ("y2", _vp),
                 ("res2", _vp), ("slabs_o", _vp), ("slabs_down", _vp), ("slabs_qkv", _vp), ("qkv_out", _vp),
                 ("cos", _vp), ("sin", _vp), ("positions", _vp), ("slots", _vp), ("k_pool", _vp), ("v_pool", _vp),
-                ("H", _c_int), ("Hkv", _c_int), ("D", _c_int), ("rot_dim", _c_int)]
+                ("H", _c_int), ("Hkv", _c_int), ("D", _c_int), ("rot_dim", _c_int), ("dtype", _c_int)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/tgis_hip.h
@@ -63,7 +63,7 @@ SIGNATURES = {
                                             ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64), _vp]),
     "tgis_gptq_dequant_f16": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp]),
     "tgis_dense_prepared_bytes": (_c_i64, [_c_i64, _c_i64]),
-    "tgis_dense_prepare": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _vp, _vp]),
+    "tgis_dense_prepare": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _c_int, _vp, _vp]),
     "tgis_dense_gemm_workspace_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
     "tgis_dense_gemm": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int,
                                  _c_int, _vp, _c_i64, _vp]),
@@ -83,7 +83,7 @@ SIGNATURES = {
     "tgis_rope_kv_write_prefill": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_i64,
                                             _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "tgis_attn_num_splits": (_c_int, [_c_i64, _c_int, _c_int, _c_i64, _c_i64]),
-    "tgis_attn_workspace_bytes": (_c_i64, [_c_i64, _c_int, _c_int, _c_int]),
+    "tgis_attn_workspace_bytes": (_c_i64, [_c_i64, _c_int, _c_int, _c_int, _c_int]),
     "tgis_attn_paged": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_int, _c_int,
                                  _c_int, _c_i64, _c_i64, _c_f, _c_int, _c_int, _vp, _c_i64, _vp]),
     "tgis_act_mul": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_int, _c_int, _vp]),
@@ -91,7 +91,7 @@ SIGNATURES = {
     "tgis_embedding": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _vp]),
     "tgis_decode_slots": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp]),
     "tgis_argmax_logprob": (_c_int, [_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _vp, _vp, _vp]),
-    "tgis_llama_decode_tail_slab_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
+    "tgis_llama_decode_tail_slab_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64, _c_i64]),
     "tgis_llama_decode_tail_fits": (_c_int, [ctypes.POINTER(TailArgs)]),
     "tgis_llama_decode_tail": (_c_int, [ctypes.POINTER(TailArgs), _vp]),
     "tgis_llama_decode_tail_status": (_c_int, [_c_int]),
@@ -327,18 +327,20 @@ def gptq_dequant(w: GptqWeight) -> torch.Tensor:
 
 # ---- dense ------------------------------------------------------------------------------------------
 class DenseWeight:
-    """torch-Linear weight [N,K] repacked into MFMA tile order."""
+    """torch-Linear weight [N,K] repacked into MFMA tile order.  gate_up=True: the weight is the Llama MLP's
+    [gate | up] and the image interleaves the pairs for the SiLU*up epilogue (dense_gemm(act=2))."""
 
-    def __init__(self, weight: torch.Tensor):
+    def __init__(self, weight: torch.Tensor, gate_up: bool = False):
         lib = load_library()
         assert weight.dim() == 2
         self.N, self.K = weight.shape
         self.dtype = weight.dtype
+        self.flags = 1 if gate_up else 0
         weight = weight.contiguous()
         self.image = torch.empty(lib.tgis_dense_prepared_bytes(self.N, self.K), dtype=torch.uint8,
                                  device=weight.device)
-        _check(lib.tgis_dense_prepare(_ptr(weight), self.N, self.K, dtype_code(weight.dtype), _ptr(self.image),
-                                      _stream()), "tgis_dense_prepare")
+        _check(lib.tgis_dense_prepare(_ptr(weight), self.N, self.K, dtype_code(weight.dtype), self.flags,
+                                      _ptr(self.image), _stream()), "tgis_dense_prepare")
         torch.cuda.current_stream().synchronize()
 
     def workspace_bytes(self, M: int) -> int:
@@ -349,9 +351,11 @@ def dense_gemm(x: torch.Tensor, w: DenseWeight, ws: Workspace, bias=None, out_f3
                out=None) -> torch.Tensor:
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == w.dtype
     M = x.shape[0]
-    assert x.shape[1] == (2 * w.K if act else w.K)
+    assert x.shape[1] == (2 * w.K if act == 1 else w.K)
+    assert (act == 2) == bool(w.flags & 1), "act 2 runs on (and only on) a gate|up image"
     if out is None:
-        out = torch.empty((M, w.N), dtype=torch.float32 if out_f32 else w.dtype, device=x.device)
+        out = torch.empty((M, w.N // 2 if act == 2 else w.N), dtype=torch.float32 if out_f32 else w.dtype,
+                          device=x.device)
     ws.ensure(w.workspace_bytes(M))
     _check(
         load_library().tgis_dense_gemm(_ptr(x), x.stride(0), _ptr(w.image), _ptr(bias), _ptr(out), out.stride(0), M,
@@ -478,8 +482,8 @@ def attn_num_splits(B: int, Hkv: int, H: int, max_q_len: int, max_ctx: int) -> i
     return load_library().tgis_attn_num_splits(B, Hkv, H, max_q_len, max_ctx)
 
 
-def attn_workspace_bytes(total_q: int, H: int, D: int, num_splits: int) -> int:
-    return load_library().tgis_attn_workspace_bytes(total_q, H, D, num_splits)
+def attn_workspace_bytes(total_q: int, H: int, Hkv: int, D: int, num_splits: int) -> int:
+    return load_library().tgis_attn_workspace_bytes(total_q, H, Hkv, D, num_splits)
 
 
 def attn_paged(q, ld_q: int, k_pool, v_pool, block_tables, ctx_lens, cu_seqlens_q, out, B: int, H: int, Hkv: int,
@@ -497,17 +501,27 @@ def attn_paged(q, ld_q: int, k_pool, v_pool, block_tables, ctx_lens, cu_seqlens_
 
 
 # ---- persistent decode tail ---------------------------------------------------------------------------------------
-def _tail_linear(w: "GptqWeight", bias) -> TailLinear:
-    return TailLinear(w.image.data_ptr(), _ptr(bias), w.K, w.N, w.groups)
+def _groups(w) -> int:
+    """tgis_tail_linear.groups: the GPTQ group count, 0 for a dense image."""
+    return 0 if isinstance(w, DenseWeight) else w.groups
+
+
+def _tail_linear(w, bias) -> TailLinear:
+    return TailLinear(w.image.data_ptr(), _ptr(bias), w.K, w.N, _groups(w))
 
 
 class DecodeTail:
     """Static part of one layer's tgis_llama_decode_tail call (weights of o_proj / gate_up / down, the post-attention
-    norm, and the next layer's input norm + qkv — or the final norm when there is no next layer)."""
+    norm, and the next layer's input norm + qkv — or the final norm when there is no next layer).  The four linears
+    are either all GptqWeight (fp16; gate_up prepared with the fused SiLU*up epilogue) or all DenseWeight."""
 
     def __init__(self, o_proj, gate_up, down, norm1_weight, norm2_weight, eps: float, qkv=None, H=0, Hkv=0, D=0,
                  rot_dim=0):
-        # each linear is (GptqWeight, bias or None); gate_up must have been prepared with gate_up=True
+        # each linear is (weight image, bias or None)
+        self.dense = isinstance(o_proj[0], DenseWeight)
+        kinds = {isinstance(l[0], DenseWeight) for l in (o_proj, gate_up, down, qkv) if l is not None}
+        assert kinds == {self.dense}, "the decode tail runs layers whose linears are all int4 or all dense"
+        self.dtype = o_proj[0].dtype if self.dense else torch.float16
         assert gate_up[0].flags & 1, "the decode tail needs the fused SiLU*up gate_up image"
         self.keep = (o_proj, gate_up, down, qkv, norm1_weight, norm2_weight)  # the struct only holds raw pointers
         self.o_proj, self.gate_up, self.down, self.qkv = o_proj, gate_up, down, qkv
@@ -520,7 +534,7 @@ class DecodeTail:
         got = self._slab_elems.get(M)
         if got is None:
             lib = load_library()
-            got = tuple(lib.tgis_llama_decode_tail_slab_bytes(M, w.K, w.N) // 4 if w is not None else 0
+            got = tuple(lib.tgis_llama_decode_tail_slab_bytes(M, w.K, w.N, _groups(w)) // 4 if w is not None else 0
                         for w in (self.o_proj[0], self.down[0], self.qkv[0] if self.qkv else None))
             self._slab_elems[M] = got
         return got
@@ -528,16 +542,16 @@ class DecodeTail:
     def run(self, attn_out: torch.Tensor, residual: torch.Tensor, cos=None, sin=None, positions=None, slots=None,
             k_pool=None, v_pool=None):
         """Returns (y2, res2, qkv_out or None)."""
-        assert attn_out.dtype == torch.float16 and attn_out.is_contiguous() and residual.is_contiguous()
+        assert attn_out.dtype == self.dtype and attn_out.is_contiguous() and residual.is_contiguous()
         M, dev = attn_out.shape[0], attn_out.device
         E, I = self.hidden, self.down[0].K
-        h = lambda n: torch.empty((M, n), dtype=torch.float16, device=dev)  # noqa: E731
+        h = lambda n: torch.empty((M, n), dtype=self.dtype, device=dev)  # noqa: E731
         y1, res1, act, y2, res2 = h(E), h(E), h(I), h(E), h(E)
         so, sd, sq = self.slab_elems(M)
         f = lambda n: torch.empty(n, dtype=torch.float32, device=dev)  # noqa: E731
         slabs_o, slabs_d = f(so), f(sd)
         a = TailArgs()
-        a.M, a.hidden, a.eps = M, E, self.eps
+        a.M, a.hidden, a.eps, a.dtype = M, E, self.eps, dtype_code(self.dtype)
         a.attn_out, a.residual_in = _ptr(attn_out), _ptr(residual)
         a.o_proj, a.gate_up, a.down = _tail_linear(*self.o_proj), _tail_linear(*self.gate_up), _tail_linear(*self.down)
         a.norm1_weight, a.norm2_weight = _ptr(self.norm1_weight), _ptr(self.norm2_weight)
@@ -555,13 +569,14 @@ class DecodeTail:
         return y2, res2, qkv_out
 
 
-def decode_tail_fits(M: int, o_proj: "GptqWeight", gate_up: "GptqWeight", down: "GptqWeight", qkv=None) -> bool:
-    """Can tgis_llama_decode_tail run a layer with these linears (shapes and plans only)?"""
+def decode_tail_fits(M: int, o_proj, gate_up, down, qkv=None) -> bool:
+    """Can tgis_llama_decode_tail run a layer with these linears (GptqWeight or DenseWeight; shapes and plans only)?"""
     a = TailArgs()
     a.M, a.hidden = M, o_proj.N
+    a.dtype = dtype_code(o_proj.dtype) if isinstance(o_proj, DenseWeight) else F16
     for name, w in (("o_proj", o_proj), ("gate_up", gate_up), ("down", down), ("qkv", qkv)):
         if w is not None:
-            setattr(a, name, TailLinear(None, None, w.K, w.N, w.groups))
+            setattr(a, name, TailLinear(None, None, w.K, w.N, _groups(w)))
     return bool(load_library().tgis_llama_decode_tail_fits(ctypes.byref(a)))
 
 

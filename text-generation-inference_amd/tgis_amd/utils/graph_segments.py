@@ -10,6 +10,8 @@ shared memory pool, so addresses stay fixed across replays.
 `collective(fn)` is the only hook the layers need: eager mode runs `fn` at once; while a `SegmentedGraph` records it
 closes the open segment, runs `fn` on the recording stream (so that communicators, workspaces and the allocator see
 the same sequence as a replay) and opens the next segment."""
+import contextlib
+import gc
 from typing import Callable, List, Optional, Union
 
 import torch
@@ -44,6 +46,22 @@ def _run_timed(fn: Callable[[], None]) -> None:
     fn()
     b.record()
     _timed.append((a, b))
+
+
+@contextlib.contextmanager
+def no_gc_during_capture():
+    """The cyclic collector must not run while a stream is capturing: a finaliser it triggers (an older model's graphs
+    and private pool, a retired workspace) calls into the HIP runtime, which invalidates the capture or aborts the
+    process.  torch.cuda.graph() no longer collects on entry by default (torch >= 2.9), so collect here, then keep
+    the collector off until the capture has ended."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def collective(fn: Callable[[], None]) -> None:
@@ -87,7 +105,7 @@ class SegmentedGraph:
             raise RuntimeError("nested SegmentedGraph.record")
         torch.cuda.synchronize(self.device)
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self.stream):
+        with no_gc_during_capture(), torch.cuda.stream(self.stream):
             _recording = self
             try:
                 self._begin()

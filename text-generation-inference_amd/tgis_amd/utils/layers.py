@@ -42,8 +42,26 @@ class FastLinear:
         self.bias = bias
         self.prepared = native.DenseWeight(weight)
         self.out_features, self.in_features = weight.shape
+        self._gate_up = False
+
+    @property
+    def gate_up(self) -> bool:
+        return self._gate_up
+
+    @gate_up.setter
+    def gate_up(self, on: bool):
+        """Set by LlamaMLP on the fused [gate | up] projection: SiLU(gate)*up then runs in the GEMM epilogue (the image
+        is rebuilt with interleaved pairs; the checkpoint-layout weight stays for the large-M library path)."""
+        if bool(on) != self._gate_up:
+            self._gate_up = bool(on)
+            self.prepared = native.DenseWeight(self.weight, gate_up=self._gate_up)
 
     def forward(self, x: torch.Tensor, act: int = 0, out_f32: bool = False, partial: bool = False) -> torch.Tensor:
+        if self._gate_up:
+            # output is the activated [M, I] tensor
+            if x.shape[0] <= SKINNY_MAX_M:
+                return native.dense_gemm(x, self.prepared, workspace(x.device), bias=self.bias, act=2)
+            return native.act_mul(F.linear(x, self.weight, self.bias), self.out_features // 2)
         if partial and x.shape[0] <= native.PARTIAL_MAX_M and DEFER_REDUCE and not out_f32:
             # the split-K sum (and the bias) is finished by the consumer kernel (add+norm / rope): no reduce launch
             return native.dense_gemm_partial(x, self.prepared, bias=self.bias, act=act)

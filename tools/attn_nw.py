@@ -1,4 +1,15 @@
-import sys; sys.path.insert(0,'tools'); sys.path.insert(0,'text-generation-inference_amd')
-import microbench as mb
-mb.bench_attn(32,32,32,128,1024)
-mb.bench_attn(32,32,32,128,1024, ns=2)
+"""Decode attention: waves per block x key splits sweep (TGIS_ATTN_NW is read per launch).  GPU box only.
+    python tools/attn_nw.py B H Hkv D ctx"""
+import os
+import sys
+
+sys.path.insert(0, "tools")
+sys.path.insert(0, "text-generation-inference_amd")
+import microbench as mb  # noqa: E402
+
+B, H, Hkv, D, ctx = (int(v) for v in sys.argv[1:6]) if len(sys.argv) >= 6 else (16, 32, 4, 64, 512)
+for nw in (4, 8, 16):
+    os.environ["TGIS_ATTN_NW"] = str(nw)
+    for ns in (1, 2, 4, 8, 16, 32):
+        print(f"NW={nw:2d} ", end="")
+        mb.bench_attn(B, H, Hkv, D, ctx, ns=ns, sets=6)

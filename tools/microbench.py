@@ -74,7 +74,7 @@ def bench_attn(B, H, Hkv, D, ctx, sets=2, ns=None):
     out = torch.empty(B, H * D, device=dev, dtype=torch.float16)
     if ns is None:
         ns = nat.attn_num_splits(B, Hkv, H, 1, ctx)
-    ws = nat.Workspace(nat.attn_workspace_bytes(B, H, D, ns), dev)
+    ws = nat.Workspace(nat.attn_workspace_bytes(B, H, Hkv, D, ns), dev)
     t = timeit(lambda i: nat.attn_paged(q, H * D, pools[i][0], pools[i][1], bt, ctxl, cu, out, B, H, Hkv, D, 1, ctx,
                                         D ** -0.5, ns, ws), sets)
     byts = B * ctx * 2 * Hkv * D * 2

@@ -1,5 +1,7 @@
-"""Phase timeline of the persistent decode tail (csrc/decode_tail.hip) at cfg3 shapes: per workgroup s_memrealtime
-stamps at the phase edges -> median / max duration of every phase and barrier.  GPU box only."""
+"""Phase timeline of the persistent decode tail (csrc/decode_tail.hip): per workgroup s_memrealtime stamps at the
+phase edges -> median / max duration of every phase and barrier.  GPU box only.
+    python tools/tail_trace.py            cfg3 shapes (Llama-2-7B, int4 GPTQ, fp16)
+    python tools/tail_trace.py dense      cfg2 shapes (TinyLlama-1.1B, dense bf16);  M=<rows> in the environment"""
 import ctypes
 import os
 import sys
@@ -12,7 +14,11 @@ sys.path.insert(0, os.path.join(ROOT, "text-generation-inference_amd"))
 from tgis_amd import native as nat  # noqa: E402
 
 dev = torch.device("cuda:0")
-E, I, H, D, M = 4096, 11008, 32, 128, int(os.getenv("M", "32"))
+DENSE = len(sys.argv) > 1 and sys.argv[1] == "dense"
+if DENSE:
+    E, I, H, HKV, D, M, DT = 2048, 5632, 32, 4, 64, int(os.getenv("M", "16")), torch.bfloat16
+else:
+    E, I, H, HKV, D, M, DT = 4096, 11008, 32, 32, 128, int(os.getenv("M", "32")), torch.float16
 
 
 def gptq(K, N, gate_up=False):
@@ -23,28 +29,34 @@ def gptq(K, N, gate_up=False):
     return nat.GptqWeight(qw, qz, sc, None, 4, 128, gate_up=gate_up)
 
 
+def dense(K, N, gate_up=False):
+    return nat.DenseWeight((torch.randn(N, K, device=dev) * 0.02).to(DT), gate_up=gate_up)
+
+
+lin = dense if DENSE else gptq
 sets = []
-for _ in range(3):  # rotate weight sets: no Infinity-Cache residency
-    sets.append(nat.DecodeTail((gptq(E, E), None), (gptq(E, 2 * I, True), None), (gptq(I, E), None),
-                               torch.ones(E, device=dev).half(), torch.ones(E, device=dev).half(), 1e-5,
-                               qkv=(gptq(E, 3 * E), None), H=H, Hkv=H, D=D, rot_dim=D))
-attn = torch.randn(M, E, device=dev).half() * 0.1
-res = torch.randn(M, E, device=dev).half()
-cos = torch.ones(2048, D // 2, device=dev).half()
-sin = torch.zeros(2048, D // 2, device=dev).half()
+for _ in range(12 if DENSE else 3):  # rotate weight sets: no Infinity-Cache residency (88 MB per dense set)
+    sets.append(nat.DecodeTail((lin(E, E), None), (lin(E, 2 * I, True), None), (lin(I, E), None),
+                               torch.ones(E, device=dev).to(DT), torch.ones(E, device=dev).to(DT), 1e-5,
+                               qkv=(lin(E, (H + 2 * HKV) * D), None), H=H, Hkv=HKV, D=D, rot_dim=D))
+NS = len(sets)
+attn = (torch.randn(M, E, device=dev) * 0.1).to(DT)
+res = torch.randn(M, E, device=dev).to(DT)
+cos = torch.ones(2048, D // 2, device=dev).to(DT)
+sin = torch.zeros(2048, D // 2, device=dev).to(DT)
 pos = torch.arange(M, dtype=torch.int32, device=dev)
 slots = torch.arange(M, dtype=torch.int32, device=dev) * 32
-kp = torch.zeros(M + 1, H, 32 * D, device=dev).half()
+kp = torch.zeros(M + 1, HKV, 32 * D, device=dev).to(DT)
 vp = torch.zeros_like(kp)
 lib = nat.load_library()
-for i in range(6):
-    sets[i % 3].run(attn, res, cos, sin, pos, slots, kp, vp)
+for i in range(2 * NS):
+    sets[i % NS].run(attn, res, cos, sin, pos, slots, kp, vp)
 torch.cuda.synchronize()
 lib.tgis_llama_decode_tail_trace(1, None, 0)
 names = ["o_proj", "bar", "norm1", "bar", "gate_up", "bar", "down", "bar", "norm2", "bar", "qkv", "bar", "rope"]
 acc = []
 for i in range(12):
-    sets[i % 3].run(attn, res, cos, sin, pos, slots, kp, vp)
+    sets[i % NS].run(attn, res, cos, sin, pos, slots, kp, vp)
     torch.cuda.synchronize()
     buf = np.zeros((256, 16), dtype=np.int64)
     lib.tgis_llama_decode_tail_trace(-1, buf.ctypes.data_as(ctypes.c_void_p), 256)
