@@ -17,6 +17,7 @@
 // same lane, so the only cross-lane traffic per page is the 2-step row-max exchange.
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 #include "attention_args.h"
 
@@ -24,13 +25,15 @@ namespace {
 
 
 // NW = waves per workgroup (the key range of a block is dealt page-by-page to its waves)
-template <typename T, int D, int NW, int CH>
+// PIPE: two pages of K/V loads in flight per wave (twice the fragment registers)
+template <typename T, int D, int NW, int CH, bool PIPE>
 __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     using V8 = typename VecT<T>::x8;
     constexpr int KS = D / 32;  // k-steps of the QK^T MFMA
     constexpr int NB = D / 16;  // 16-row blocks of O^T
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: the block-table reads become scalar loads
     const int col = lane & 15, c = lane >> 4;
     const int qt = blockIdx.x;
     const int hk = blockIdx.y / a.HCB, hc0 = (blockIdx.y % a.HCB) * CH;  // first 16-head chunk of this block
@@ -81,13 +84,10 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     }
 
     const int32_t* btrow = a.bt + (int64_t)b * a.max_pages;
-    int p = pbeg + w;
-    int pg = (p < pend) ? btrow[p] : 0;
-    for (; p < pend; p += NW) {
-        const int pg_next = (p + NW < pend) ? btrow[p + NW] : 0;
+    // one page of K (two 16-token halves x KS k-steps) and V^T (NB 16-row blocks): 16 KiB per wave at D = 128
+    auto load_page = [&](const int pg, V8 (&kf)[2][KS], V8 (&vf)[NB]) {
         const T* kb = reinterpret_cast<const T*>(a.kpool) + ((int64_t)pg * a.Hkv + hk) * (32 * D) + lane * 8;
         const T* vb = reinterpret_cast<const T*>(a.vpool) + ((int64_t)pg * a.Hkv + hk) * (32 * D) + col * 32 + c * 8;
-        V8 kf[2][KS], vf[NB];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -95,7 +95,16 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
                 reinterpret_cast<const V8*>(kb + t * (16 * D) + ks * 512));
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) vf[nb] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(vb + nb * 512));
-
+    };
+    // FULL: every key of the page is visible to every valid column (all but the last page of a decode step) — no
+    // masks.  The softmax reference m[ch] is only moved when a tile maximum exceeds it by more than 2^RESCALE_LOG2
+    // (then P <= 2^RESCALE_LOG2, harmless in fp32 / f16 / bf16): the rescale of O — whose accumulators live in AGPRs,
+    // so every multiply costs a read and a write-back as well — and of the running sum then runs in a handful of
+    // pages per sequence instead of every page, behind a wave-uniform branch.  (MQA, 3 chunks: 697 -> ~250 VALU
+    // instructions per page; the loop is issue-bound, not HBM-bound: tools/attn_nw.py.)
+    constexpr float RESCALE_LOG2 = 8.f;
+    auto apply_page = [&](const int p, const V8 (&kf)[2][KS], const V8 (&vf)[NB], auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         const int kp0 = p * 32 + c * 4;
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) {
@@ -113,34 +122,75 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = s[t][r] * a.scale_log2;
-                    v = (kp0 + t * 16 + r < kmax[ch]) ? v : NEG_BIG;
+                    if (!FULL) v = (kp0 + t * 16 + r < kmax[ch]) ? v : NEG_BIG;
                     s[t][r] = v;
                     tmax = fmaxf(tmax, v);
                 }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m[ch], tmax);
-            const float alpha = exp2f(m[ch] - m_new);
-            m[ch] = m_new;
+            if (__any(tmax > m[ch] + RESCALE_LOG2)) {
+                const float m_new = fmaxf(m[ch], tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m[ch] - m_new);  // 0 while m is still NEG_BIG
+                m[ch] = m_new;
+                lsum[ch] *= alpha;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) o[ch][nb] *= alpha;
+            }
+            const float mref = m[ch];
             V8 pf;
             float psum = 0.f;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    float pv = __builtin_amdgcn_exp2f(s[t][r] - mref);
                     // masked entries contribute exactly 0 even while m is still NEG_BIG
-                    float pv = (s[t][r] > 0.5f * NEG_BIG) ? exp2f(s[t][r] - m_new) : 0.f;
+                    if (!FULL) pv = (s[t][r] > 0.5f * NEG_BIG) ? pv : 0.f;
                     T pt = from_f32<T>(pv);
                     pf[t * 4 + r] = pt;
                     psum += to_f32(pt);  // normaliser from the rounded P, as flash-attention does
                 }
-            lsum[ch] = lsum[ch] * alpha + psum;
+            lsum[ch] += psum;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                o[ch][nb] *= alpha;
-                o[ch][nb] = mfma16(vf[nb], pf, o[ch][nb]);
-            }
+            for (int nb = 0; nb < NB; ++nb) o[ch][nb] = mfma16(vf[nb], pf, o[ch][nb]);
         }
+    };
+    // pages below kfull are visible in full to every column of the tile (the tile's first token sees kfull keys)
+    const int kfull = ctx - q_len + t0 + 1;
+    int p = pbeg + w;
+    if (PIPE) {
+        // Pairs of fully visible pages with two pages of loads in flight: the next page's 16 KiB are requested before
+        // the current page is applied.  The body is straight-line (every load it issues is needed, the trip count is
+        // wave-uniform) so that hipcc keeps counted vmcnt waits; with a conditional prefetch it drains to vmcnt(0)
+        // before every load and nothing overlaps (measured: no gain).  What is left — an odd full page, the
+        // partly visible last page — takes the plain loop below.
+        const int nfull = (kfull >> 5) > p ? min(((kfull >> 5) - p + NW - 1) / NW, (pend - p + NW - 1) / NW) : 0;
+        const int npairs = p < pend ? nfull >> 1 : 0;
+        if (npairs > 0) {
+            V8 kfa[2][KS], vfa[NB], kfb[2][KS], vfb[NB];
+            load_page(btrow[p], kfa, vfa);
+            for (int i = 0; i + 1 < npairs; ++i) {
+                load_page(btrow[p + NW], kfb, vfb);
+                apply_page(p, kfa, vfa, std::true_type{});
+                load_page(btrow[p + 2 * NW], kfa, vfa);
+                apply_page(p + NW, kfb, vfb, std::true_type{});
+                p += 2 * NW;
+            }
+            load_page(btrow[p + NW], kfb, vfb);
+            apply_page(p, kfa, vfa, std::true_type{});
+            apply_page(p + NW, kfb, vfb, std::true_type{});
+            p += 2 * NW;
+        }
+    }
+    int pg = (p < pend) ? btrow[p] : 0;
+    for (; p < pend; p += NW) {
+        const int pg_next = (p + NW < pend) ? btrow[p + NW] : 0;
+        V8 kf[2][KS], vf[NB];
+        load_page(pg, kf, vf);
+        if (p * 32 + 32 <= kfull)
+            apply_page(p, kf, vf, std::true_type{});
+        else
+            apply_page(p, kf, vf, std::false_type{});
         pg = pg_next;
     }
 
@@ -233,37 +283,80 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     }
     __syncthreads();
     if (!*lastp) return;
-    for (int item = tid; item < CH * 16 * (D / 8); item += 64 * NW) {
-        const int j = item & 15, dc = (item >> 4) % (D / 8), ch = item / (16 * (D / 8));
-        const int hc = hc0 + ch;
-        const int tqj = j / a.Gp, gj = j % a.Gp;
-        if (!(gj < a.Gc && hc * 16 + gj < a.G && t0 + tqj < q_len)) continue;
-        const int64_t rec0 = (((int64_t)grp * CH + ch) * 16 + j) * a.NS;
-        float mstar = NEG_BIG;
-        for (int s2 = 0; s2 < a.NS; ++s2) {
-            const f32x4 ml = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, (uint32_t)((rec0 + s2) * 16), 0, 16));
-            mstar = fmaxf(mstar, ml[0]);
-        }
-        float l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int s2 = 0; s2 < a.NS; ++s2) {
-            const f32x4 ml = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, (uint32_t)((rec0 + s2) * 16), 0, 16));
-            const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, (uint32_t)(((rec0 + s2) * D + dc * 8) * 4), 0, 16));
-            const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, (uint32_t)(((rec0 + s2) * D + dc * 8 + 4) * 4), 0, 16));
-            const float f = exp2f(ml[0] - mstar);
-            l += ml[1] * f;
+    // IB of this thread's items x MB splits are loaded before the first use (one round trip per batch instead of one
+    // per split and item); batches are folded with the usual running-maximum rescale.
+    constexpr int ITEMS = CH * 16 * (D / 8), THREADS = 64 * NW, ITER = (ITEMS + THREADS - 1) / THREADS;
+    constexpr int IB = ITER < 4 ? ITER : 4, MB = 8 / IB;  // <= 8 records (96 registers) in flight
+    for (int it0 = 0; it0 < ITER; it0 += IB) {
+        bool ok[IB];
+        int64_t rec0[IB];
+        int dcs[IB];
+        float mrun[IB], lrun[IB], acc[IB][8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[e] += lo[e] * f;
-                acc[e + 4] += hi[e] * f;
+        for (int it = 0; it < IB; ++it) {
+            const int item = tid + (it0 + it) * THREADS;
+            const int j = item & 15, dc = (item >> 4) % (D / 8), ch = item / (16 * (D / 8));
+            const int tqj = j / a.Gp, gj = j % a.Gp;
+            ok[it] = item < ITEMS && gj < a.Gc && (hc0 + ch) * 16 + gj < a.G && t0 + tqj < q_len;
+            rec0[it] = ok[it] ? (((int64_t)grp * CH + ch) * 16 + j) * a.NS : 0;  // (clamped: the loads stay in bounds)
+            dcs[it] = dc;
+            mrun[it] = NEG_BIG;
+            lrun[it] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[it][e] = 0.f;
+        }
+        for (int s0 = 0; s0 < a.NS; s0 += MB) {
+            f32x4 ml[IB][MB], lo[IB][MB], hi[IB][MB];
+#pragma unroll
+            for (int it = 0; it < IB; ++it)
+#pragma unroll
+                for (int k = 0; k < MB; ++k) {
+                    const int64_t rec = rec0[it] + min(s0 + k, a.NS - 1);
+                    ml[it][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, (uint32_t)(rec * 16), 0, 16));
+                    lo[it][k] = __builtin_bit_cast(
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, (uint32_t)((rec * D + dcs[it] * 8) * 4), 0, 16));
+                    hi[it][k] = __builtin_bit_cast(
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, (uint32_t)((rec * D + dcs[it] * 8 + 4) * 4), 0, 16));
+                }
+#pragma unroll
+            for (int it = 0; it < IB; ++it) {
+                float mb = mrun[it];
+#pragma unroll
+                for (int k = 0; k < MB; ++k)
+                    if (s0 + k < a.NS) mb = fmaxf(mb, ml[it][k][0]);
+                const float fr = exp2f(mrun[it] - mb);  // 0 for the first batch (mrun = NEG_BIG)
+                mrun[it] = mb;
+                lrun[it] *= fr;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[it][e] *= fr;
+#pragma unroll
+                for (int k = 0; k < MB; ++k) {
+                    if (s0 + k < a.NS) {
+                        const float f = exp2f(ml[it][k][0] - mb);
+                        lrun[it] += ml[it][k][1] * f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[it][e] += lo[it][k][e] * f;
+                            acc[it][e + 4] += hi[it][k][e] * f;
+                        }
+                    }
+                }
             }
         }
-        const float inv = l > 0.f ? 1.f / l : 0.f;
-        V8 ov;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(acc[e] * inv);
-        const int64_t tokidx = q0 + t0 + tqj;
-        const int headj = hk * a.G + hc * 16 + gj;
-        st16(reinterpret_cast<T*>(a.out) + (tokidx * a.H + headj) * D + dc * 8, ov);
+        for (int it = 0; it < IB; ++it) {
+            if (!ok[it]) continue;
+            const int item = tid + (it0 + it) * THREADS;
+            const int j = item & 15, ch = item / (16 * (D / 8));
+            const int tqj = j / a.Gp, gj = j % a.Gp;
+            const float inv = lrun[it] > 0.f ? 1.f / lrun[it] : 0.f;
+            V8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(acc[it][e] * inv);
+            const int64_t tokidx = q0 + t0 + tqj;
+            const int headj = hk * a.G + (hc0 + ch) * 16 + gj;
+            st16(reinterpret_cast<T*>(a.out) + (tokidx * a.H + headj) * D + dcs[it] * 8, ov);
+        }
     }
 }
 
@@ -313,18 +406,36 @@ static AttnGeom geom(int H, int Hkv) {
 static bool wide_decode_blocks(int64_t groups, int ch) { return ch == 1 && groups < 256; }
 
 // 16-head chunks one decode block serves (register budget: 3 sets of O accumulators at D = 128)
-static int chunks_per_block(int HC, int64_t max_q_len) { return (max_q_len == 1 && HC > 1) ? std::min(HC, 3) : 1; }
+static int chunks_per_block(int HC, int64_t max_q_len) {
+    if (const char* e = getenv("TGIS_ATTN_CH")) {  // tuning hook (tools/attn_nw.py)
+        const int v = atoi(e);
+        if (v >= 1 && v <= 3) return (max_q_len == 1 && HC > 1) ? std::min(HC, v) : 1;
+    }
+    return (max_q_len == 1 && HC > 1) ? std::min(HC, 3) : 1;
+}
 
-template <typename T, int D, int NW, int CH>
-static void launch_attn_one(const AttnArgs& a, dim3 grid, hipStream_t st) {
+template <typename T, int D, int NW, int CH, bool PIPE>
+static void launch_attn_pipe(const AttnArgs& a, dim3 grid, hipStream_t st) {
     const size_t lds = (size_t)CH * (NW * D * 16 + NW * 2 * 16) * sizeof(float);
     static bool attr = false;  // e.g. CH = 3, D = 128, NW = 4: 98 KB of combine scratch
     if (!attr && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void*)attn_paged_kernel<T, D, NW, CH>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+        (void)hipFuncSetAttribute((const void*)attn_paged_kernel<T, D, NW, CH, PIPE>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((attn_paged_kernel<T, D, NW, CH>), grid, dim3(64 * NW), lds, st, a);
+    hipLaunchKernelGGL((attn_paged_kernel<T, D, NW, CH, PIPE>), grid, dim3(64 * NW), lds, st, a);
+}
+
+// Two pages in flight where a block is alone on its CU anyway (multi-chunk blocks: nothing else there hides the load
+// latency; MQA 48:1, B=32, ctx 4096: 30.3 -> 25.8 us).  The 8-wave blocks of few-group shapes measured no different,
+// and the many-block shapes keep the small-register variant.
+template <typename T, int D, int NW, int CH>
+static void launch_attn_one(const AttnArgs& a, dim3 grid, hipStream_t st) {
+    static const int pipe_env = getenv("TGIS_ATTN_PIPE") ? atoi(getenv("TGIS_ATTN_PIPE")) : -1;  // A/B hook
+    if constexpr (CH > 1 && NW == 4) {
+        if (pipe_env != 0) return launch_attn_pipe<T, D, NW, CH, true>(a, grid, st);
+    }
+    launch_attn_pipe<T, D, NW, CH, false>(a, grid, st);
 }
 
 template <typename T, int D, int CH>
@@ -333,7 +444,6 @@ static void launch_attn_nw(const AttnArgs& a, dim3 grid, hipStream_t st, int nw)
     if (nw == 2) return launch_attn_one<T, D, 2, CH>(a, grid, st);
     if constexpr (CH == 1) {  // wide blocks: few (sequence, kv head) groups, the waves of one block share the keys
         if (nw == 8) return launch_attn_one<T, D, 8, CH>(a, grid, st);
-        if (nw == 16) return launch_attn_one<T, D, 16, CH>(a, grid, st);
     }
     launch_attn_one<T, D, 4, CH>(a, grid, st);
 }
@@ -364,18 +474,21 @@ extern "C" int tgis_attn_num_splits(int64_t B, int Hkv, int H, int64_t max_q_len
     const int ch = chunks_per_block(g.HC, max_q_len);
     int64_t base = B * Hkv * cdiv64(g.HC, ch) * q_tiles;
     int64_t pages = cdiv64(std::max<int64_t>(max_ctx, 1), 32);
-    // ~512 blocks: enough to fill 256 CUs twice; more, thinner blocks lose to the dispatch ramp and the combine pass
-    // (tools/split_sweep.py: B=32 MQA ctx 4096: 19 us at 8 splits vs 26 us at 32)
-    // (multi-chunk blocks hold three sets of accumulators: one block per CU, so one round of 256 —
-    //  tools/attn_mqa.py, 48 q heads on 1 kv head, B=32 ctx 4096: 26.7 us at 8 splits, 38 at 16, 32 at 4)
+    // single-chunk blocks, many groups: ~512 blocks fill 256 CUs twice; more, thinner blocks lose to the dispatch ramp
+    // and the merge
     int64_t ns;
     if (wide_decode_blocks(base, ch)) {
         // few (sequence, kv head) groups: 8-wave blocks, one round of <= 256 of them, >= 2 pages per wave
         // (tools/attn_nw.py, us: B=16 GQA 8:1 D=64 ctx 512: 6.8 unsplit vs 8.5 at 4 splits of 4 waves;
         //  B=1 MHA D=128 ctx 2048: 14.1 at 8 splits vs 17.7 at 16; B=4 GQA 4:1 ctx 4096: 19.0 at 8 vs 24.0 at 16)
         ns = std::min<int64_t>(cdiv64(256, base), pages / 16);
+    } else if (ch > 1) {
+        // multi-chunk blocks hold three sets of accumulators: one block per CU.  Half a round of them, each wave with
+        // >= 4 pages, beats a full round of thinner ones — the merge of the splits costs 6-8 us whatever they hold
+        // (tools/attn_nw.py, 48 q heads on 1 kv head, B=32 ctx 4096: 25.8 us at 4 splits, 29.0 at 8, 31.7 at 2)
+        ns = std::min<int64_t>(cdiv64(128, base), pages / 16);
     } else {
-        ns = cdiv64(ch > 1 ? 256 : 512, base);
+        ns = cdiv64(512, base);
         ns = std::min<int64_t>(ns, cdiv64(pages, 4));  // at least one page per wave
     }
     ns = std::max<int64_t>(1, std::min<int64_t>(ns, 64));
@@ -504,7 +617,7 @@ extern "C" int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, 
     if (max_q_len == 1 && wide_decode_blocks(nblocks / num_splits, ch)) nw = 8;
     if (const char* e = getenv("TGIS_ATTN_NW")) {
         const int v = atoi(e);
-        nw = (v == 1 || v == 2 || v == 8 || v == 16) ? v : 4;
+        nw = (v == 1 || v == 2 || v == 8) ? v : 4;
         if (ch > 1 && nw > 4) nw = 4;
     }
     TgisTimedScope timed(TGIS_OP_ATTN, st);
