@@ -211,6 +211,23 @@ int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, const void*
                     int64_t max_q_len, int64_t max_ctx, float scale, int dtype, int num_splits,
                     void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Decode step (one q token per sequence, cu_seqlens_q = 0..B) with the rotary embedding and the cache write of the new
+ * token done in the attention launch's prologue: the work of tgis_rope_kv_write[_partial] followed by tgis_attn_paged,
+ * with the same arithmetic and one launch less per layer (flash_llama_modeling.py:262-295 in one call).
+ *   qkv [B, ld_qkv] (T): the UN-rotated output of the qkv projection, or — slabs != NULL — its split-K partial sums
+ *   as left by tgis_*_gemm_partial (bias then = the projection's bias or NULL; qkv is ignored).
+ *   cos / sin NULL: no rotation (GPT-BigCode), cache write only.  k_pool / v_pool are read AND written (slots[b]).
+ * Every block computes the rotated q fragments it needs; the block that owns a sequence's last page writes the new
+ * token's k and v into it before walking its pages.  The rotated q / k are not materialised anywhere else.
+ * (Measured on MI355X: not faster than the two launches — DESIGN.md §6; the host mirror keeps them by default.) */
+int tgis_attn_decode_rope(const void* qkv, int64_t ld_qkv, const float* slabs, int num_slabs, int64_t slab_ld,
+                          const void* bias, const void* cos, const void* sin, const int32_t* positions,
+                          const int32_t* slots, int rot_dim, void* k_pool, void* v_pool,
+                          const int32_t* block_tables, int64_t max_pages, const int32_t* ctx_lens,
+                          const int32_t* cu_seqlens_q, void* out, int64_t B, int H, int Hkv, int D,
+                          int64_t max_ctx, float scale, int dtype, int num_splits, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
 /* ---- elementwise --------------------------------------------------------------------------------- */
 /* out[T,I] = act(gate_up[T,0:I]) * gate_up[T,I:2I]; act 1 = SiLU (flash_llama_modeling.py:332-335). */
 int tgis_act_mul(const void* gate_up, void* out, int64_t T, int64_t I, int act, int dtype, void* stream);

@@ -313,6 +313,81 @@ def test_split_decode_attention_merges_in_one_launch_every_time(nat, gpu_device,
         assert torch.equal(run(qs[i & 1], ns), first[i & 1]), f"launch {i}: the merged result changed"
 
 
+@pytest.mark.parametrize("dtype,B,H,Hkv,D,ctx,rotary,partial", [
+    (torch.float16, 32, 32, 32, 128, 300, True, True),     # cfg3 shape class: MHA, split-K qkv slabs
+    (torch.bfloat16, 16, 32, 4, 64, 512, True, True),      # cfg2: GQA 8:1, D = 64, 8-wave blocks
+    (torch.float16, 3, 32, 8, 128, 1500, True, False),     # key splits, qkv as a finished tensor (the TP path)
+    (torch.bfloat16, 4, 48, 1, 128, 700, False, True),     # GPT-BigCode: MQA in three chunks, no rotation
+    (torch.float16, 2, 16, 16, 64, 33, True, True),        # the new token opens a page
+    (torch.float16, 5, 32, 8, 128, 1, True, False),        # first decode position: the cache holds only the new token
+])
+def test_decode_attention_with_rope_and_cache_write_in_its_prologue(nat, gpu_device, dtype, B, H, Hkv, D, ctx, rotary,
+                                                                    partial):
+    """tgis_attn_decode_rope against tgis_rope_kv_write[_partial] + tgis_attn_paged on the same inputs: same attention
+    output and the same bytes in the KV pages (the new token's k / v at its slot, everything else untouched)."""
+    g = torch.Generator().manual_seed(B * 7 + H + ctx)
+    lens = [max(1, ctx - 5 * i) for i in range(B)]
+    pages_per = [(l + 31) // 32 for l in lens]
+    total_pages = sum(pages_per) + 1
+    bt = torch.zeros((B, max(pages_per)), dtype=torch.int32)
+    perm = torch.randperm(total_pages - 1, generator=g) + 1
+    o = 0
+    for b in range(B):
+        bt[b, :pages_per[b]] = perm[o:o + pages_per[b]].int()
+        o += pages_per[b]
+    N = (H + 2 * Hkv) * D
+    # cache contents of the earlier tokens (written through the stand-alone kernel, no rotation needed for the test)
+    Tall = sum(l - 1 for l in lens)
+    kpool = torch.zeros((total_pages, Hkv, 32 * D), dtype=dtype, device=gpu_device)
+    vpool = torch.zeros_like(kpool)
+    if Tall:
+        old = torch.zeros((Tall, N), dtype=dtype)
+        old[:, H * D:] = torch.randn(Tall, 2 * Hkv * D, generator=g).to(dtype)
+        slots_old = torch.cat([bt[b, torch.arange(l - 1) // 32].long() * 32 + torch.arange(l - 1) % 32
+                               for b, l in enumerate(lens)]).int()
+        nat.rope_kv_write(old.to(gpu_device), None, None, None, slots_old.to(gpu_device), kpool, vpool, H, Hkv, D, D)
+    # the decode step's qkv projection output: as split-K slabs (two partial sums + bias) or as a tensor
+    qkv = torch.randn(B, N, generator=g)
+    bias = (torch.randn(N, generator=g) * 0.1).to(dtype) if partial else None
+    positions = torch.tensor([l - 1 for l in lens], dtype=torch.int32, device=gpu_device)
+    slots = torch.tensor([int(bt[b, (l - 1) // 32]) * 32 + (l - 1) % 32 for b, l in enumerate(lens)], dtype=torch.int32,
+                         device=gpu_device)
+    cos = sin = None
+    if rotary:
+        ang = torch.rand(max(lens) + 1, D // 2, generator=g) * 6.28
+        cos, sin = ang.cos().to(dtype).to(gpu_device), ang.sin().to(dtype).to(gpu_device)
+
+    def make_input():
+        if not partial:
+            return qkv.to(dtype).to(gpu_device)
+        S, ld = 2, N
+        slabs = torch.zeros((1, S, 32, ld), dtype=torch.float32)
+        part = torch.randn(B, N, generator=torch.Generator().manual_seed(1))
+        slabs[0, 0, :B] = part
+        slabs[0, 1, :B] = qkv - part
+        p = nat.Partial(slabs.reshape(-1).to(gpu_device), S, ld, B, N, bias.to(gpu_device))
+        p.dtype = dtype
+        return p
+
+    ns = nat.attn_num_splits(B, Hkv, H, 1, max(lens))
+    ws = nat.Workspace(max(4096, nat.attn_workspace_bytes(B, H, Hkv, D, ns)), gpu_device)
+    btd, ctxd = bt.to(gpu_device), torch.tensor(lens, dtype=torch.int32).to(gpu_device)
+    cuq = torch.arange(B + 1, dtype=torch.int32, device=gpu_device)
+    # separate launches
+    k1, v1 = kpool.clone(), vpool.clone()
+    rot = nat.rope_kv_write(make_input(), cos, sin, positions, slots, k1, v1, H, Hkv, D, D)
+    out1 = torch.empty((B, H * D), dtype=dtype, device=gpu_device)
+    nat.attn_paged(rot, rot.stride(0), k1, v1, btd, ctxd, cuq, out1, B, H, Hkv, D, 1, max(lens), D ** -0.5, ns, ws)
+    # one launch
+    k2, v2 = kpool.clone(), vpool.clone()
+    out2 = torch.empty((B, H * D), dtype=dtype, device=gpu_device)
+    nat.attn_decode_rope(make_input(), cos, sin, positions, slots, k2, v2, btd, ctxd, cuq, out2, B, H, Hkv, D, D,
+                         max(lens), D ** -0.5, ns, ws)
+    assert torch.equal(k1, k2) and torch.equal(v1, v2), "the KV pages written in the attention prologue differ"
+    assert not torch.equal(k2, kpool), "nothing was written"
+    assert torch.equal(out1, out2), f"attention output differs (max {(out1.float() - out2.float()).abs().max().item()})"
+
+
 # ---- elementwise / sampling ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_act_mul_gelu_embedding(nat, gpu_device, dtype):

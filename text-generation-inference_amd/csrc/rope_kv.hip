@@ -9,39 +9,9 @@
 //   V: [D][32], token tok at column (i>>2)*8 + tile*4 + (i&3), i = tok&15 -> V^T A-fragments likewise
 #include <algorithm>
 #include "common.h"
+#include "kv_layout.h"
 
 namespace {
-
-__device__ __forceinline__ int64_t k_off(int tok, int d, int D) {
-    return ((int64_t)(((tok >> 4) * (D >> 3) + (d >> 3)) * 16 + (tok & 15)) << 3) + (d & 7);
-}
-__device__ __forceinline__ int v_col(int tok) {
-    int i = tok & 15;
-    return (i >> 2) * 8 + (tok >> 4) * 4 + (i & 3);
-}
-
-template <typename T> struct PartialIn {
-    const float* slabs;  // [S][32][slab_ld] fp32 split-K partial sums of the qkv GEMM, or nullptr
-    int S;
-    int64_t slab_ld;
-    const T* bias;
-};
-
-template <typename T>
-__device__ __forceinline__ typename VecT<T>::x8 load_chunk(const T* hp, int64_t t, int col, const PartialIn<T>& pin) {
-    using V8 = typename VecT<T>::x8;
-    if (pin.slabs == nullptr) return ld16<V8>(hp);
-    f32x4 lo, hi;
-    sum_slabs8(pin.slabs + ((t >> 5) * pin.S * 32 + (t & 31)) * pin.slab_ld + col, 32 * pin.slab_ld, pin.S, lo, hi);
-    V8 a;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float b0 = pin.bias ? to_f32(pin.bias[col + e]) : 0.f, b1 = pin.bias ? to_f32(pin.bias[col + 4 + e]) : 0.f;
-        a[e] = from_f32<T>(lo[e] + b0);
-        a[e + 4] = from_f32<T>(hi[e] + b1);
-    }
-    return a;
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void rope_kv_kernel(T* qkv, int64_t ld, const T* __restrict__ cosb,

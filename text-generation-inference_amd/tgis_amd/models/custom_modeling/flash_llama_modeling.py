@@ -79,6 +79,12 @@ class KVArgs:
 # 67 us against 64 us for the seven launches it replaces (profiles/r02_decode_tail.md) — the six grid barriers cost
 # what the saved dispatch ramps and the cross-barrier weight prefetch gain.
 DECODE_TAIL = os.getenv("TGIS_DECODE_TAIL", "false").lower() in ("1", "true")
+# TGIS_FUSED_ROPE_ATTN=true: decode runs the rotary embedding + cache write of the new token in the attention launch's
+# prologue (tgis_attn_decode_rope, bit-identical results).  Off by default: measured slower than the stand-alone
+# rope_kv_write launch in front of tgis_attn_paged on every config (cfg3 5.37 vs 4.92 ms/step, cfg2 1.21 vs 1.15, cfg5
+# 8.52 vs 7.78; tools/attn_fused_bench.py) — the prologue's dependent loads delay every block's first K/V load, and the
+# new token's scattered v stores collide with the same launch's reads of that page.
+FUSED_ROPE_ATTN = os.getenv("TGIS_FUSED_ROPE_ATTN", "false").lower() in ("1", "true")
 
 
 class LlamaRMSNorm:
@@ -159,9 +165,29 @@ class FlashLlamaAttention:
                           attn_output, B, H, Hkv, D, kv.max_q_len, kv.max_ctx, self.softmax_scale, kv.num_splits, ws)
         return attn_output
 
+    def decode_attend(self, hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id: int, kv: KVArgs):
+        """Decode step: qkv GEMM, then ONE launch that finishes its split-K sum, rotates q and k, writes the new token's
+        k / v into its page and attends (tgis_attn_decode_rope) — the reference's :251-295 without a launch of its own
+        for the rotary embedding and the cache write."""
+        H, Hkv, D = self.num_heads, self.num_key_value_heads, self.head_size
+        qkv = self.query_key_value(hidden_states, partial=True)
+        B = kv.block_tables.shape[0]
+        attn_output = torch.empty((B, H * D), dtype=hidden_states.dtype, device=hidden_states.device)
+        ws = None
+        if kv.num_splits > 1:
+            from tgis_amd.utils.layers import workspace
+            ws = workspace(hidden_states.device)
+            ws.ensure(native.attn_workspace_bytes(B, H, Hkv, D, kv.num_splits))
+        return native.attn_decode_rope(qkv, cos, sin, position_ids, kv.slots, kv.cache.k_pool(layer_id),
+                                       kv.cache.v_pool(layer_id), kv.block_tables, kv.ctx_lens, cu_seqlens_q,
+                                       attn_output, B, H, Hkv, D, D, kv.max_ctx, self.softmax_scale, kv.num_splits, ws)
+
     def forward(self, hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id: int, kv: KVArgs):
-        qkv = self.project_qkv(hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id, kv)
-        attn_output = self.attend(qkv, cu_seqlens_q, layer_id, kv)
+        if FUSED_ROPE_ATTN and kv.max_q_len == 1 and kv.slots is not None and not kv.fresh_prefill:
+            attn_output = self.decode_attend(hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id, kv)
+        else:
+            qkv = self.project_qkv(hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id, kv)
+            attn_output = self.attend(qkv, cu_seqlens_q, layer_id, kv)
         # may be a native.Partial: the following fused add+RMSNorm finishes the split-K sum
         return self.o_proj(attn_output, partial=True)
 

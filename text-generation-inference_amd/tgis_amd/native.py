@@ -86,6 +86,9 @@ SIGNATURES = {
     "tgis_attn_workspace_bytes": (_c_i64, [_c_i64, _c_int, _c_int, _c_int, _c_int]),
     "tgis_attn_paged": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_int, _c_int,
                                  _c_int, _c_i64, _c_i64, _c_f, _c_int, _c_int, _vp, _c_i64, _vp]),
+    "tgis_attn_decode_rope": (_c_int, [_vp, _c_i64, _vp, _c_int, _c_i64, _vp, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp,
+                                       _c_i64, _vp, _vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f, _c_int,
+                                       _c_int, _vp, _c_i64, _vp]),
     "tgis_act_mul": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_int, _c_int, _vp]),
     "tgis_gelu": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _vp]),
     "tgis_embedding": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _vp]),
@@ -497,6 +500,28 @@ def attn_paged(q, ld_q: int, k_pool, v_pool, block_tables, ctx_lens, cu_seqlens_
                                        block_tables.shape[1], _ptr(ctx_lens), _ptr(cu_seqlens_q), _ptr(out), B, H,
                                        Hkv, D, max_q_len, max_ctx, float(scale), dtype_code(q.dtype), num_splits,
                                        wptr, wbytes, _stream()), "tgis_attn_paged")
+    return out
+
+
+def attn_decode_rope(qkv, cos, sin, positions, slots, k_pool, v_pool, block_tables, ctx_lens, cu_seqlens_q, out, B: int,
+                     H: int, Hkv: int, D: int, rot_dim: int, max_ctx: int, scale: float, num_splits: int,
+                     ws: Optional[Workspace]):
+    """Decode attention straight from the qkv projection's output (a tensor or a Partial): rotary embedding of q and k
+    and the cache write of the new token happen in the attention launch.  out [B, H*D]."""
+    assert block_tables.dtype == torch.int32 and ctx_lens.dtype == torch.int32 and cu_seqlens_q.dtype == torch.int32
+    assert block_tables.is_contiguous() and out.is_contiguous()
+    wptr, wbytes = (ws.ptr, ws.nbytes) if ws is not None else (None, 0)
+    if isinstance(qkv, Partial):
+        qp, ld, slabs, S, sld, bias, dt = None, 0, _ptr(qkv.slabs), qkv.S, qkv.ld, _ptr(qkv.bias), qkv.dtype
+    else:
+        assert qkv.dim() == 2 and qkv.stride(1) == 1
+        qp, ld, slabs, S, sld, bias, dt = _ptr(qkv), qkv.stride(0), None, 0, 0, None, qkv.dtype
+    _check(
+        load_library().tgis_attn_decode_rope(qp, ld, slabs, S, sld, bias, _ptr(cos), _ptr(sin), _ptr(positions),
+                                             _ptr(slots), rot_dim, _ptr(k_pool), _ptr(v_pool), _ptr(block_tables),
+                                             block_tables.shape[1], _ptr(ctx_lens), _ptr(cu_seqlens_q), _ptr(out), B, H,
+                                             Hkv, D, max_ctx, float(scale), dtype_code(dt), num_splits, wptr, wbytes,
+                                             _stream()), "tgis_attn_decode_rope")
     return out
 
 
