@@ -393,6 +393,36 @@ def test_batch_larger_than_one_row_slab_matches_oracle(gpu_device, variant):
     assert lm.kv_cache.free_pages == lm.kv_cache.num_pages, "pages leaked"
 
 
+def test_graph_pool_outlives_the_eviction_of_its_last_graph(gpu_device):
+    """All decode graphs of a model share one memory pool.  With room for ONE graph every new (batch size, width) key
+    evicts the only graph the pool holds before the next capture starts — the allocator drops a pool whose last graph
+    died, so the capture must not go on using its handle.  Alternate two batch sizes, three times; every step's logits
+    must equal the eager run's."""
+    cfg = TinyLlamaConfig(max_position_embeddings=512)
+    tensors = tiny_llama_tensors(cfg, seed=6, quantize="gptq", groupsize=64)
+    rng = np.random.default_rng(29)
+    pa = [rng.integers(3, cfg.vocab_size, size=n).tolist() for n in (30, 12)]
+    pb = [rng.integers(3, cfg.vocab_size, size=n).tolist() for n in (9, 21, 14)]
+
+    def run(lm, tok):
+        out = []
+        for rep in range(3):
+            for prompts in (pa, pb):
+                tap = _LogitTap(lm)
+                batch = _from_pb(lm, tok, _pb(prompts, 6, first_id=10 * rep, batch_id=rep))
+                out += [_step(lm, batch, tap, first=(i == 0))[1] for i in range(4)]
+                batch.release()
+        return out
+
+    lm, tok = _build(cfg, tensors, "gptq", 64, torch.float16, use_graphs=True)
+    lm.max_graphs = 1
+    got = run(lm, tok)
+    assert lm.use_graphs and len(lm._graphs) == 1
+    lm_e, tok_e = _build(cfg, tensors, "gptq", 64, torch.float16, use_graphs=False)
+    for i, (a, b) in enumerate(zip(got, run(lm_e, tok_e))):
+        assert np.array_equal(a, b), f"step {i}: replay after an eviction differs from the eager step"
+
+
 def test_captured_graphs_survive_table_and_workspace_growth(gpu_device):
     """Decode graphs hold raw device pointers to the rope tables and to the shared workspace.  Capture a short-context
     graph, then serve a 2100-token request (rope tables grow past their first 2048 positions) and grow the workspace,

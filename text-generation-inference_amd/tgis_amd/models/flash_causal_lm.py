@@ -549,6 +549,9 @@ class FlashCausalLM(Model):
         if g is None:
             while len(self._graphs) >= self.max_graphs:
                 self._graphs.popitem(last=False)
+            if not self._graphs and self.graph_pool is not None:
+                # the allocator retires a pool with its last graph: captures that follow start a new one
+                self.graph_pool = torch.cuda.graph_pool_handle()
             g = self._graphs[key] = _DecodeGraph(self, *key)
         else:
             self._graphs.move_to_end(key)
