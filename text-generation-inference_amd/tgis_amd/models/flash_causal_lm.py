@@ -362,6 +362,10 @@ class _DecodeGraph:
                     self.lm.graph_mode = "segments"
                     g = None
             if g is None:
+                if not any(d.graph is not None for d in self.lm._graphs.values()):
+                    # no captured graph holds the pool (e.g. the full capture above failed and took the pool's only
+                    # graph with it): the allocator has retired it, start a new one
+                    self.lm.graph_pool = torch.cuda.graph_pool_handle()
                 g = SegmentedGraph(self.lm.device, pool=self.lm.graph_pool)
                 try:
                     self.logits, self.ids, self.logprobs = g.record(self._step)
