@@ -350,8 +350,11 @@ def test_decode_attention_at_workload_context(gpu_device, name, B, H, Hkv, D, ct
     assert err <= tol, f"{name}: max err {err:.5f} > {tol} (splits {ns})"
 
 
-@pytest.mark.parametrize("K,N,act", [(4096, 12288, 0), (4096, 22016, 2), (11008, 4096, 0), (4096, 4096, 0)])
-@pytest.mark.parametrize("M", [65, 100, 128, 257, 1000])
+@pytest.mark.parametrize("K,N,act,M", [(K, N, act, M) for (K, N, act) in [(4096, 12288, 0), (4096, 22016, 2),
+                                                                          (11008, 4096, 0), (4096, 4096, 0)]
+                                       for M in (65, 100, 128, 257, 1000)] +
+                         # two 32-column tiles per wave (256-column blocks): taken once >= 384 such blocks remain
+                         [(4096, 12288, 0, 2100), (4096, 22016, 2, 1100), (11008, 4096, 0, 3000), (4096, 4096, 0, 3072)])
 def test_gptq_tall_kernel_matches_oracle(gpu_device, K, N, act, M):
     """64 < M: the fused tall kernel (one dequantisation per 128 rows, no scratch copy of W) at the cfg3 shapes, every
     epilogue (plain, split-K + reduce, SiLU * up on the interleaved image, deferred slabs), ragged last row block."""

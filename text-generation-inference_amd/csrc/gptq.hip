@@ -107,8 +107,12 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
 constexpr int TKC = 128;       // k per x chunk (2 k64-steps)
 constexpr int TRS = TKC + 8;   // LDS row stride in halves (+16 B: conflict-free ds_read_b128 of A fragments)
 
-template <int BMR, int ACT>
-__global__ __launch_bounds__(256) void gptq_gemm_tall_kernel(GemmArgs a) {
+// TW = 32-column tiles per wave.  With one tile every MFMA needs its own 1 KiB A fragment from LDS: eight resident waves x
+// one ds_read_b128 per 32-cycle MFMA is the whole LDS bandwidth of the CU.  With two tiles an A fragment feeds two MFMAs
+// (256-column blocks, half the LDS traffic per flop); the kernel is held to 256 registers so that two blocks still share
+// a CU.
+template <int BMR, int ACT, int TW>
+__global__ __launch_bounds__(256, 2) void gptq_gemm_tall_kernel(GemmArgs a) {
     constexpr int BM = 32 * BMR;
     constexpr int NJ = BM * 16 / 256;  // 16-byte x pieces per thread and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -118,25 +122,30 @@ __global__ __launch_bounds__(256) void gptq_gemm_tall_kernel(GemmArgs a) {
     const int m0 = blockIdx.y * BM;
     const int mrows = min(BM, a.M - m0);
     const int split = blockIdx.z;
-    const int nt_raw = blockIdx.x * 4 + w;
-    const int nt = min(nt_raw, a.NT - 1);
+    const int nt_raw0 = (blockIdx.x * 4 + w) * TW;
     const int ksteps = a.K >> 6;                     // K % 64 == 0 (host)
     const int per = a.KR >> 6;                       // k64-steps per split (multiple of 2)
     const int ks0 = split * per, ks1 = min(ksteps, ks0 + per);
     const int nchunks = (ks1 - ks0 + 1) >> 1;        // block-uniform
 
-    const char* wtile = reinterpret_cast<const char*>(a.prep) + (int64_t)nt * a.KS * 1024;
-    const char* sztile = reinterpret_cast<const char*>(a.prep + a.offB) + (int64_t)nt * a.G * 128;
+    const char* wtile[TW];
+    const char* sztile[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const int nt = min(nt_raw0 + t, a.NT - 1);
+        wtile[t] = reinterpret_cast<const char*>(a.prep) + (int64_t)nt * a.KS * 1024;
+        sztile[t] = reinterpret_cast<const char*>(a.prep + a.offB) + (int64_t)nt * a.G * 128;
+    }
     const uint32_t woff = lane * 16, szoff = (lane & 31) * 4;
-    auto sz_at = [&](int ks) -> uint32_t {
+    auto sz_at = [&](int t, int ks) -> uint32_t {
         const int g = min(ks >> a.spg_shift, a.G - 1);
-        const char* p = sztile + (int64_t)g * 128;
+        const char* p = sztile[t] + (int64_t)g * 128;
         PIN_SGPR(p);
         const uint32_t v = *(const GLOBAL_AS uint32_t*)(p + szoff);
         return ks < ks1 ? v : 0u;  // steps past the split's range add zeros
     };
-    auto w_at = [&](int ks) -> u32x4 {
-        const char* p = wtile + (int64_t)min(ks, ksteps - 1) * 1024;
+    auto w_at = [&](int t, int ks) -> u32x4 {
+        const char* p = wtile[t] + (int64_t)min(ks, ksteps - 1) * 1024;
         PIN_SGPR(p);
         return __builtin_nontemporal_load((const GLOBAL_AS u32x4*)(p + woff));
     };
@@ -164,18 +173,24 @@ __global__ __launch_bounds__(256) void gptq_gemm_tall_kernel(GemmArgs a) {
     uint32_t EXr = 0x64006400u, M0r = 0x000F000Fu, M1r = 0x00F000F0u;
     asm volatile("" : "+v"(EXr));
     asm volatile("" : "+s"(M0r), "+s"(M1r));
-    f32x16 acc[BMR];
+    f32x16 acc[TW][BMR];
 #pragma unroll
-    for (int rb = 0; rb < BMR; ++rb) acc[rb] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int rb = 0; rb < BMR; ++rb) acc[t][rb] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int xoff = (lane & 31) * TRS + (lane >> 5) * 32;
 
     stage_load(0);
-    u32x4 wq[4];
-    uint32_t szr[4];
+    u32x4 wq[TW][4];
+    uint32_t szr[TW][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) szr[s] = sz_at(ks0 + s);
+    for (int t = 0; t < TW; ++t)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wq[s] = w_at(ks0 + s);
+        for (int s = 0; s < 4; ++s) szr[t][s] = sz_at(t, ks0 + s);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < TW; ++t) wq[t][s] = w_at(t, ks0 + s);
     stage_store(0);
     __syncthreads();
 
@@ -184,33 +199,41 @@ __global__ __launch_bounds__(256) void gptq_gemm_tall_kernel(GemmArgs a) {
         constexpr int SB = decltype(sb_tag)::value;
         const bool more = chunk + 1 < nchunks;  // block-uniform
         if (more) stage_load(chunk + 1);
-        uint32_t szn[2];
+        uint32_t szn[TW][2];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) szn[s2] = sz_at(ks0 + chunk * 2 + s2 + 4);
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) szn[t][s2] = sz_at(t, ks0 + chunk * 2 + s2 + 4);
         const f16* xbuf = xs + (chunk & 1) * (BM * TRS) + xoff;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int ks = ks0 + chunk * 2 + s2;
-            const u32x4 cur = wq[SB + s2];
-            const f16x2 szh = __builtin_bit_cast(f16x2, szr[SB + s2]);
-            const f16 zc1 = szh[1];
-            const f16 zd1 = (f16)960.f - zc1;
-            const f16x2 zc = {zc1, zc1}, zd = {zd1, zd1}, sc = {szh[0], szh[0]};
-            f16x8 b[4];
+            f16x8 b[TW][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) b[i] = gptq::dequant8(cur[i], zc, zd, sc, EXr, M0r, M1r);
-            wq[SB + s2] = w_at(ks + 4);
+            for (int t = 0; t < TW; ++t) {
+                const u32x4 cur = wq[t][SB + s2];
+                const f16x2 szh = __builtin_bit_cast(f16x2, szr[t][SB + s2]);
+                const f16 zc1 = szh[1];
+                const f16 zd1 = (f16)960.f - zc1;
+                const f16x2 zc = {zc1, zc1}, zd = {zd1, zd1}, sc = {szh[0], szh[0]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[t][i] = gptq::dequant8(cur[i], zc, zd, sc, EXr, M0r, M1r);
+                wq[t][SB + s2] = w_at(t, ks + 4);
+            }
             const f16* xk = xbuf + s2 * 64;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int rb = 0; rb < BMR; ++rb) {
                     const f16x8 av = ld16<f16x8>(xk + rb * (32 * TRS) + i * 8);
-                    acc[rb] = mfma32(av, b[i], acc[rb]);
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) acc[t][rb] = mfma32(av, b[t][i], acc[t][rb]);
                 }
         }
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) szr[SB + s2] = szn[s2];
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) szr[t][SB + s2] = szn[t][s2];
         if (more) stage_store((chunk + 1) & 1);
         __syncthreads();
     };
@@ -224,8 +247,11 @@ __global__ __launch_bounds__(256) void gptq_gemm_tall_kernel(GemmArgs a) {
     if (chunk < nchunks) chunk_body(chunk, I0{});
 
     // ---- epilogue: lane holds rows m = 32 rb + (r&3) + 8 (r>>2) + 4 (lane>>5) of column n = nt * 32 + (lane & 31) ----
-    if (nt_raw >= a.NT) return;
     const int c = lane & 31;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+    const int nt = nt_raw0 + t;
+    if (nt >= a.NT) break;
     if (ACT == 2) {
         const int half = a.N >> 1;
         const int j = nt * 16 + (c & 15);
@@ -235,7 +261,7 @@ __global__ __launch_bounds__(256) void gptq_gemm_tall_kernel(GemmArgs a) {
         for (int rb = 0; rb < BMR; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float mine = (float)(f16)(acc[rb][r] + bv);
+                const float mine = (float)(f16)(acc[t][rb][r] + bv);
                 const float other = __shfl_xor(mine, 16, 64);
                 const int m = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (c < 16 && m < mrows) {
@@ -243,7 +269,7 @@ __global__ __launch_bounds__(256) void gptq_gemm_tall_kernel(GemmArgs a) {
                     a.out[(int64_t)(m0 + m) * a.ldo + j] = (f16)((float)(f16)sl * other);
                 }
             }
-        return;
+        continue;
     }
     const int n = nt * 32 + c;
     if (a.S == 1 && !a.partial) {
@@ -253,7 +279,7 @@ __global__ __launch_bounds__(256) void gptq_gemm_tall_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < mrows) a.out[(int64_t)(m0 + m) * a.ldo + n] = (f16)(acc[rb][r] + bv);
+                if (m < mrows) a.out[(int64_t)(m0 + m) * a.ldo + n] = (f16)(acc[t][rb][r] + bv);
             }
     } else {
         // slabs in 32-row units [unit][S][32][NP], unit = row / 32 (what norm / rope / the reduce kernel index)
@@ -266,9 +292,10 @@ __global__ __launch_bounds__(256) void gptq_gemm_tall_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                sl[(int64_t)m * np] = acc[rb][r];
+                sl[(int64_t)m * np] = acc[t][rb][r];
             }
         }
+    }
     }
 }
 
@@ -373,11 +400,14 @@ extern "C" int tgis_gptq_prepare(const int32_t* qweight, const int32_t* qzeros, 
 
 // ---- tall kernel: when, and how it is cut ---------------------------------------------------------------------------
 // Rows from which the tall kernel replaces the 64-row streaming passes, and up to which it replaces dequantise + library
-// GEMM.  tools/tall_sweep.py on MI355X, cfg3 shapes (us, tall / passes / library incl. its dequantisation): gate_up M=128
-// 48 / 52 / 164, M=256 75 / 82 / 172, M=512 132 / 164 / 206, M=1024 254 / - / 297, M=2048 466 / - / 510, M=4096 886 / - /
-// 865; qkv M=256 54 / 49 / 85, M=512 74 / 82 / 100, M=1024 127 / - / 135, M=2048 249 / - / 226.  Up to 256 rows the passes
-// (with their deferred split-K sums) stay; from 257 to 3072 rows the tall kernel runs at 700-900 TFLOP/s without a scratch
-// copy of W; above, hipBLASLt on the dequantised copy (1.0-1.1 PFLOP/s) wins.
+// GEMM.  tools/tall_sweep.py on MI355X, cfg3 shapes (profiles/r02_tall_sweep.log; us, tall / passes / library incl. its
+// dequantisation): gate_up M=256 75 / 82 / 172, M=512 132 / 164 / 206, M=1024 235 / - / 304, M=2048 437 / - / 508, M=3072
+// 640 / - / 659, M=4096 814 / - / 871; qkv M=512 81 / 82 / 100, M=1024 133 / - / 138, M=2048 227 / - / 230, M=3072 339 / -
+// / 331, M=4096 423 / - / 381; the four GEMMs of a layer together: M=2048 954 / - / 1027, M=3072 1444 / - / 1373, M=4096
+// 1752 / - / 1713, M=8192 3441 / - / 3056.  Up to 256 rows the passes (with their deferred split-K sums) stay; from 257 to
+// 3072 rows the tall kernel runs at 0.65-0.9 PFLOP/s without a scratch copy of W; above, hipBLASLt on the dequantised
+// copy (1.1-1.2 PFLOP/s) wins by a few per cent and more.  Two 32-column tiles per wave (an A fragment from LDS feeds two
+// MFMAs; 1.0 PFLOP/s at M >= 4096) once 384 blocks of 256 columns remain; one tile per wave below.
 static int64_t tall_min_m() {
     static const int64_t v = getenv("TGIS_TALL_MIN_M") ? atoll(getenv("TGIS_TALL_MIN_M")) : 257;
     return v;
@@ -392,12 +422,15 @@ static bool tall_ok(int64_t M, int64_t K, int64_t groups, const int32_t* perm, i
     return groups == 1 || (gs % 64 == 0 && (spg & (spg - 1)) == 0);
 }
 struct TallPlan {
-    int BMR, S, KR;
+    int BMR, S, KR, TW;
 };
 static TallPlan plan_tall(int64_t M, int64_t K, int64_t N, int act) {
     TallPlan t;
     t.BMR = M > 64 ? 4 : 2;
-    const int64_t blocks = cdiv64(cdiv64(N, 32), 4) * cdiv64(M, 32 * t.BMR);
+    // two tiles per wave (256-column blocks) once that still leaves every CU a few blocks
+    t.TW = (t.BMR == 4 && cdiv64(cdiv64(N, 32), 8) * cdiv64(M, 128) >= 384) ? 2 : 1;
+    if (const char* e = getenv("TGIS_TALL_TW")) t.TW = (atoi(e) == 2 && t.BMR == 4) ? 2 : 1;
+    const int64_t blocks = cdiv64(cdiv64(N, 32), 4 * t.TW) * cdiv64(M, 32 * t.BMR);
     const int64_t kchunks = cdiv64(K, TKC);
     int64_t S = 1;
     if (act != 2 && blocks < 384) S = std::min<int64_t>(std::min<int64_t>(kchunks, 16), cdiv64(512, blocks));
@@ -442,22 +475,24 @@ static int launch_tall(const void* x, int64_t ldx, const void* prepared, const v
         for (a.spg_shift = 0; (1 << a.spg_shift) < spg; ++a.spg_shift) {}
     const int BM = 32 * tp.BMR;
     TGIS_CHECK_ARG(cdiv64(M, BM) <= 65535, "tgis_gptq_gemm: M too large for one launch");
-    dim3 grid((unsigned)cdiv64(p.NT, 4), (unsigned)cdiv64(M, BM), (unsigned)tp.S);
+    dim3 grid((unsigned)cdiv64(p.NT, 4 * tp.TW), (unsigned)cdiv64(M, BM), (unsigned)tp.S);
     const size_t lds = (size_t)2 * BM * TRS * sizeof(f16);
-#define TGIS_TALL(B, A)                                                                                       \
+#define TGIS_TALL(B, A, W)                                                                                     \
     do {                                                                                                      \
         static bool attr = false;                                                                             \
         if (!attr) {                                                                                          \
-            TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_gemm_tall_kernel<B, A>,                      \
+            TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_gemm_tall_kernel<B, A, W>,                   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * TRS * 2)); \
             attr = true;                                                                                      \
         }                                                                                                     \
-        hipLaunchKernelGGL((gptq_gemm_tall_kernel<B, A>), grid, dim3(256), lds, st, a);                       \
+        hipLaunchKernelGGL((gptq_gemm_tall_kernel<B, A, W>), grid, dim3(256), lds, st, a);                    \
     } while (0)
-    if (tp.BMR == 4) {
-        if (act == 2) TGIS_TALL(4, 2); else TGIS_TALL(4, 0);
+    if (tp.BMR == 4 && tp.TW == 2) {
+        if (act == 2) TGIS_TALL(4, 2, 2); else TGIS_TALL(4, 0, 2);
+    } else if (tp.BMR == 4) {
+        if (act == 2) TGIS_TALL(4, 2, 1); else TGIS_TALL(4, 0, 1);
     } else {
-        if (act == 2) TGIS_TALL(2, 2); else TGIS_TALL(2, 0);
+        if (act == 2) TGIS_TALL(2, 2, 1); else TGIS_TALL(2, 0, 1);
     }
 #undef TGIS_TALL
     TGIS_CHECK_LAUNCH();

@@ -1,5 +1,5 @@
-"""GPTQ linear at M > 64: the tall fused kernel vs the 64-row streaming passes (TGIS_TALL_MIN_M=huge) vs dequantise +
-library GEMM, cfg3 shapes.  GPU time per call from a captured graph.  GPU box only."""
+"""GPTQ linear at M > 64: the tall fused kernel (default rule, one and two column tiles per wave) vs the 64-row streaming
+passes (TGIS_TALL_MIN_M=huge) vs dequantise + library GEMM, cfg3 shapes.  GPU time per call from a captured graph.  GPU box only."""
 import os
 import subprocess
 import sys
@@ -25,7 +25,7 @@ for (K, N, act) in [(4096, 12288, 0), (4096, 4096, 0), (4096, 22016, 2), (11008,
         lin.append(l)
     for M in [int(m) for m in sys.argv[2].split(",")]:
         x = torch.randn(M, K, device=dev).half()
-        if mode == "lib":
+        if mode == "lib":  # (TGIS_TALL_MAX_M=0 in the environment: _large_m never routes back to the tall kernel)
             f = lambda i: (nat.act_mul(lin[i]._large_m(x), N // 2) if act == 2 else lin[i]._large_m(x))
         else:
             ws = nat.Workspace(lin[0].q_handle.workspace_bytes(M), dev)
@@ -34,7 +34,9 @@ for (K, N, act) in [(4096, 12288, 0), (4096, 4096, 0), (4096, 22016, 2), (11008,
         print(f"{mode:7s} K={K:5d} N={N:5d} act={act} M={M:5d}: {t*1e6:9.1f} us  {2*M*K*N/t/1e12:7.1f} TFLOP/s", flush=True)
 '''
 ms = sys.argv[1] if len(sys.argv) > 1 else "96,128,256,512,1024,2048,4096"
-for mode, env in (("tall", {}), ("passes", {"TGIS_TALL_MIN_M": "1000000"}), ("lib", {})):
+for mode, env in (("tall", {"TGIS_TALL_MAX_M": "1000000"}), ("tall/1", {"TGIS_TALL_MAX_M": "1000000", "TGIS_TALL_TW": "1"}),
+                  ("tall/2", {"TGIS_TALL_MAX_M": "1000000", "TGIS_TALL_TW": "2"}),
+                  ("passes", {"TGIS_TALL_MIN_M": "1000000"}), ("lib", {"TGIS_TALL_MAX_M": "0"})):
     e = dict(os.environ, **env)
     m = ms if mode != "passes" else ",".join(x for x in ms.split(",") if int(x) <= 512)
     r = subprocess.run([sys.executable, "-c", CODE, mode, m], env=e, capture_output=True, text=True)
