@@ -197,7 +197,11 @@ __global__ __launch_bounds__(256, 2) void gptq_gemm_tall_kernel(GemmArgs a) {
     // one chunk = 2 k64-steps in ring slots SB, SB + 1; the slots are refilled in place two chunks ahead
     auto chunk_body = [&](const int chunk, auto sb_tag) {
         constexpr int SB = decltype(sb_tag)::value;
+#ifdef ABL_T_NOSTAGE  // ablation (wrong results): the first x chunk forever, no per-chunk staging or barrier
+        const bool more = false;
+#else
         const bool more = chunk + 1 < nchunks;  // block-uniform
+#endif
         if (more) stage_load(chunk + 1);
         uint32_t szn[TW][2];
 #pragma unroll
@@ -217,7 +221,13 @@ __global__ __launch_bounds__(256, 2) void gptq_gemm_tall_kernel(GemmArgs a) {
                 const f16 zd1 = (f16)960.f - zc1;
                 const f16x2 zc = {zc1, zc1}, zd = {zd1, zd1}, sc = {szh[0], szh[0]};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) b[t][i] = gptq::dequant8(cur[i], zc, zd, sc, EXr, M0r, M1r);
+                for (int i = 0; i < 4; ++i) {
+#ifdef ABL_T_NODEQ  // ablation (wrong results): the packed words as they are
+                    b[t][i] = __builtin_bit_cast(f16x8, u32x4{cur[i], cur[i] ^ EXr, cur[i], cur[i]});
+#else
+                    b[t][i] = gptq::dequant8(cur[i], zc, zd, sc, EXr, M0r, M1r);
+#endif
+                }
                 wq[t][SB + s2] = w_at(t, ks + 4);
             }
             const f16* xk = xbuf + s2 * 64;
@@ -225,7 +235,11 @@ __global__ __launch_bounds__(256, 2) void gptq_gemm_tall_kernel(GemmArgs a) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int rb = 0; rb < BMR; ++rb) {
+#ifdef ABL_T_NOLDS  // ablation (wrong results): no A fragment reads
+                    const f16x8 av = b[0][(i + 1) & 3];
+#else
                     const f16x8 av = ld16<f16x8>(xk + rb * (32 * TRS) + i * 8);
+#endif
 #pragma unroll
                     for (int t = 0; t < TW; ++t) acc[t][rb] = mfma32(av, b[t][i], acc[t][rb]);
                 }
@@ -235,7 +249,9 @@ __global__ __launch_bounds__(256, 2) void gptq_gemm_tall_kernel(GemmArgs a) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) szr[t][SB + s2] = szn[t][s2];
         if (more) stage_store((chunk + 1) & 1);
+#ifndef ABL_T_NOSTAGE
         __syncthreads();
+#endif
     };
     using I0 = std::integral_constant<int, 0>;
     using I2 = std::integral_constant<int, 2>;
