@@ -147,6 +147,20 @@ def pmc_traffic(config, B, ctx_mean):
     return int(d["fetch_bytes_per_launch_corrected"] + (d.get("write_bytes_per_launch_uncalibrated") or 0))
 
 
+def pmc_gemm_traffic(config, B, ctx_mean):
+    """HBM bytes per int4-GEMM launch (average over the four shapes of a layer) from the same counter passes
+    (profiles/r*_gemm_traffic.json); null for workloads it was not collected on."""
+    if (config, B, ctx_mean) != ("llama2-7b-gptq", 32, 1024):
+        return None
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_gemm_traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    if d.get("fetch_bytes_per_launch_corrected") is None:
+        return None
+    return int(d["fetch_bytes_per_launch_corrected"] + (d.get("write_bytes_per_launch_uncalibrated") or 0))
+
+
 def bench_causal_lm_cpu(args):
     """BASELINE config 1: GPT-2 small (124 M, random init, fp32) through CausalLMBatch / CausalLM.generate_token on the
     hf_transformers engine, CPU, batch 4, prompts of 16 tokens.  A step = one NextToken-equivalent generate_token call.
@@ -383,7 +397,8 @@ def main():
                 roofline_gemm = {"bound": "hbm", "kernel": ("gptq_gemm_kernel" if quantize == "gptq" else "dense_gemm_kernel")
                                  + f" ({per_step:.0f} launches per step)",
                                  "achieved": round(g_bytes / g_avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(g_bytes / g_avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                 "frac": round(g_bytes / g_avg_s / 1e9 / HBM_PEAK_GBS, 4),
+                                 "traffic": pmc_gemm_traffic(args.config, B, ctx_mean),
                                  "launches": int(n_gemm), "avg_launch_us": round(g_avg_s * 1e6, 2),
                                  "algorithmic_bytes_per_launch": int(g_bytes)}
 

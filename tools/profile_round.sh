@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile on the GPU box (gpurun -- tools/profile_round.sh r01):
 #   1. rocprofv3 --kernel-trace --stats over a short bench.py run  -> gpurun_out/<tag>_kernel_stats.csv
-#   2. two counter passes (FETCH_SIZE, WRITE_SIZE; counters only)  -> gpurun_out/<tag>_attn_traffic.json
+#   2. two counter passes (FETCH_SIZE, WRITE_SIZE; counters only)  -> gpurun_out/<tag>_attn_traffic.json, <tag>_gemm_traffic.json
 # Copy both into profiles/ afterwards (gpurun_out/ is scratch).
 TAG=${1:-r01}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -50,5 +50,22 @@ res = {"kernel": "attn_paged_kernel (decode)", "command": "$CMD".replace("$REPO/
        "write_bytes_per_launch_uncalibrated": None if wa is None else wa * 1024}
 json.dump(res, open(f"{out}/{tag}_attn_traffic.json", "w"), indent=1)
 print(json.dumps(res))
+# 3. the same for the int4 streaming GEMM: average over all of its decode launches (the four shapes of a layer)
+def gemm_counter(dirname, name):
+    vals = []
+    for f in glob.glob(out + f"/{dirname}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "gptq_gemm_kernel<" in r["Kernel_Name"] and r["Counter_Name"] == name:
+                vals.append(float(r["Counter_Value"]))
+    return vals
+gf, gw = gemm_counter("prof_fetch", "FETCH_SIZE"), gemm_counter("prof_write", "WRITE_SIZE")
+if gf:
+    resg = {"kernel": "gptq_gemm_kernel (all decode launches: qkv, o_proj, gate_up, down)", "launches": len(gf),
+            "FETCH_SIZE_KB_per_launch_raw": sum(gf) / len(gf),
+            "WRITE_SIZE_KB_per_launch_raw": (sum(gw) / len(gw)) if gw else None,
+            "fetch_bytes_per_launch_corrected": sum(gf) / len(gf) * 1024 * 2,
+            "write_bytes_per_launch_uncalibrated": (sum(gw) / len(gw) * 1024) if gw else None}
+    json.dump(resg, open(f"{out}/{tag}_gemm_traffic.json", "w"), indent=1)
+    print(json.dumps(resg))
 PY
 head -12 $OUT/${TAG}_kernel_stats.csv | cut -c1-220
