@@ -115,6 +115,26 @@ int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void* prepared,
                                int64_t K, int64_t N, int64_t groups, int act, float* slabs, int64_t slabs_bytes,
                                int* num_slabs, int64_t* slab_ld, void* stream);
 
+/* ---- "lean" decode GEMM (round 3) -------------------------------------------------------------------------------
+ * Same contract as tgis_gptq_gemm_f16 / tgis_gptq_gemm_f16_partial (the gemm_half_q_half call of
+ * utils/gptq/exllamav2.py:139-144) for the shapes tgis_gptq_lean_ok() accepts — 1 <= M <= 32, group size 128, no
+ * act-order, act 0 or 2 — on the SAME prepared image.  The nibbles go to the MFMA as 1024 + q / 64 + q (one VALU op per
+ * pair instead of the 13-op dequantisation); the offsets and zero points are cancelled by one extra MFMA per 128-row
+ * group whose operand is built from row sums of x, and the scale is applied once per group in fp32.  (q - z) * s is
+ * therefore exact in fp32 here (exllamav2 rounds it to f16 once): results agree with tgis_gptq_gemm_f16 to that rounding.
+ *
+ * xs: fp32 [M][ldxs][2] — per row and 16 consecutive columns of x the pair {sum of x[k] over k % 4 < 2, sum over
+ * k % 4 >= 2} — written by the producer of x: tgis_rmsnorm_residual*_xs, the act = 2 epilogue of this GEMM (xs_out, the
+ * sums of its own [M, N/2] output for the down projection) or tgis_xsum_f16 for any other f16 matrix. */
+int tgis_gptq_lean_ok(int64_t M, int64_t K, int64_t N, int64_t groups, int act_order, int act);
+int tgis_xsum_f16(const void* x, int64_t ldx, float* xs, int64_t ldxs, int64_t M, int64_t K, void* stream);
+int tgis_gptq_gemm_f16_lean(const void* x, int64_t ldx, const float* xs, int64_t ldxs, const void* prepared,
+                            const void* bias, void* out, int64_t ldo, float* xs_out, int64_t M, int64_t K, int64_t N,
+                            int64_t groups, int act, void* workspace, int64_t workspace_bytes, void* stream);
+int tgis_gptq_gemm_f16_partial_lean(const void* x, int64_t ldx, const float* xs, int64_t ldxs, const void* prepared,
+                                    int64_t M, int64_t K, int64_t N, int64_t groups, float* slabs, int64_t slabs_bytes,
+                                    int* num_slabs, int64_t* slab_ld, void* stream);
+
 /* Full dequantisation to a dense f16 [K,N] matrix (row-major), the "temp_dq" path the reference
  * uses for M > 50 before a library GEMM (exllamav2.py:65-66,87). */
 int tgis_gptq_dequant_f16(const void* prepared, void* w_out, int64_t K, int64_t N, int64_t groups,

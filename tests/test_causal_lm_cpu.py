@@ -239,3 +239,55 @@ def test_get_model_dispatch_honours_the_deployment_framework(tmp_path, lm, monke
         monkeypatch.delenv("FLASH_ATTENTION")
         with pytest.raises(ModuleNotFoundError):
             get_model(str(tmp_path), None, "no_such_engine", "float32", None, 128)
+
+
+def test_servicer_runs_the_padded_batch_type(lm):
+    """The gRPC servicer drops batches through `release()` (health check, failed step): the padded batch type answers it,
+    so the cfg1 / `hf_transformers` shard passes the router's health probe and a failing step surfaces its own error
+    (reference server.py:105-180: the health-check batch is generated and discarded)."""
+    import asyncio
+    import tempfile
+
+    import grpc
+
+    from tgis_amd.cache import Cache
+    from tgis_amd.pb import generate_pb2 as pb2
+    from tgis_amd.pb import generate_pb2_grpc
+    from tgis_amd.server import HEALTHCHECK_BATCH_ID, MemoryScalingModel, TextGenerationService
+
+    async def run():
+        with tempfile.TemporaryDirectory() as d:
+            url = f"unix://{d}/shard-0"
+            server = grpc.aio.server()
+            svc = TextGenerationService(lm, Cache(), [url], MemoryScalingModel(1000))
+            generate_pb2_grpc.add_TextGenerationServiceServicer_to_server(svc, server)
+            server.add_insecure_port(url)
+            await server.start()
+            async with grpc.aio.insecure_channel(url) as ch:
+                stub = generate_pb2_grpc.TextGenerationServiceStub(ch)
+                probe = _requests([[5, 6, 7]], 2, batch_id=HEALTHCHECK_BATCH_ID)
+                r = await stub.Prefill(pb2.PrefillRequest(batch=probe))
+                assert len(r.result.output_tokens) == 1 and len(svc.cache) == 0
+                # a normal batch: prefill, one decode step, then finished
+                r = await stub.Prefill(pb2.PrefillRequest(batch=_requests([[5, 6, 7], [8, 9]], 3, batch_id=1)))
+                assert [t.request_id for t in r.result.output_tokens] == [0, 1] and svc.cache.keys() == [1]
+                cb = pb2.CachedBatch(batch_id=1)
+                cb.status.completed_ids.extend([])
+                r = await stub.NextToken(pb2.NextTokenRequest(batches=[cb]))
+                assert len(r.result.output_tokens) == 2
+                # a failing step reports ITS error (not an AttributeError from the clean-up) and drops the batch
+                real = lm.generate_token
+
+                def boom(*a, **k):
+                    raise RuntimeError("HIP out of memory. (injected)")
+
+                lm.generate_token = boom
+                try:
+                    with pytest.raises(grpc.aio.AioRpcError) as e:
+                        await stub.NextToken(pb2.NextTokenRequest(batches=[cb]))
+                    assert "injected" in (e.value.details() or "")
+                finally:
+                    lm.generate_token = real
+            await server.stop(0)
+
+    asyncio.run(run())

@@ -339,6 +339,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16_kernel(const float* __r
     }
 }
 
+}  // namespace
+
+// shared with gptq_lean.hip (declared in gptq_gemm_body.h)
+int gptq::reduce_slabs(const float* slabs, const f16* bias, f16* out, int64_t ldo, int M, int N, int NP, int S,
+                       hipStream_t st) {
+    dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 4), 256), (unsigned)cdiv64(M, 32));
+    hipLaunchKernelGGL(splitk_reduce_f16_kernel, rgrid, dim3(256), 0, st, slabs, bias, out, ldo, M, N, NP, S);
+    TGIS_CHECK_LAUNCH();
+    return TGIS_OK;
+}
+
+namespace {
+
 __global__ void gptq_dequant_kernel(const uint8_t* __restrict__ prep, int64_t offB, f16* __restrict__ wout,
                                     int K, int N, int G, int gs, int NT, int KS, int flags) {
     // one thread per prepared int32 (8 k of one column)

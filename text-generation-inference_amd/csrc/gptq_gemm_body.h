@@ -667,6 +667,9 @@ static inline GemmPlan plan_gemm(int64_t K, int64_t N, int act = 0, int64_t M = 
     return {(int)(KRc * KC), (int)S, WK, TN, MR};
 }
 
+// sum of the S split-K slabs (+ bias) -> f16, fixed order (gptq.hip)
+int reduce_slabs(const float* slabs, const f16* bias, f16* out, int64_t ldo, int M, int N, int NP, int S, hipStream_t st);
+
 // slabs are stored in 32-row units; a 64-row pass always writes both of its units
 static inline int64_t slab_bytes(int64_t M, int64_t N, int S) {
     return S > 1 ? cdiv64(M, 64) * 2 * S * 32 * cdiv64(N, 32) * 32 * 4 : 0;

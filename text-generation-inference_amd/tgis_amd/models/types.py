@@ -61,3 +61,8 @@ class Batch(abc.ABC):
 
     def compact(self) -> None:
         """Give back over-allocated storage, if the batch type keeps any (optional)."""
+
+    def release(self) -> None:
+        """Return device resources the batch owns outside its tensors (KV pages of the paged batch).  The servicer calls
+        this on every batch it drops — after a failed step, a health check or an emptied prune — so every batch type
+        answers it; batches that own nothing but tensors (the padded `CausalLMBatch`) have nothing to do."""

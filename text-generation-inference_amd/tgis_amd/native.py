@@ -62,6 +62,12 @@ SIGNATURES = {
     "tgis_gptq_gemm_f16_partial": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_i64,
                                             ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64), _vp]),
     "tgis_gptq_dequant_f16": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp]),
+    "tgis_gptq_lean_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int]),
+    "tgis_xsum_f16": (_c_int, [_vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64, _vp]),
+    "tgis_gptq_gemm_f16_lean": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64,
+                                         _c_i64, _c_int, _vp, _c_i64, _vp]),
+    "tgis_gptq_gemm_f16_partial_lean": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp,
+                                                 _c_i64, _vp, _vp, _vp]),
     "tgis_dense_prepared_bytes": (_c_i64, [_c_i64, _c_i64]),
     "tgis_dense_prepare": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _c_int, _vp, _vp]),
     "tgis_dense_gemm_workspace_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
@@ -318,6 +324,70 @@ def gptq_gemm_partial(x: torch.Tensor, w: GptqWeight, bias=None, act: int = 0) -
                                        w.groups, act, _ptr(slabs), nbytes, None, None, _stream()),
         "tgis_gptq_gemm_f16_partial")
     return Partial(slabs, S, ld, M, w.N, bias)
+
+
+# ---- lean decode GEMM: x travels with the row sums its producer computed ---------------------------------------------
+def xs_of(x: torch.Tensor) -> Optional[torch.Tensor]:
+    """The row-sum side tensor `[M, K/16, 2]` fp32 a producer kernel attached to its f16 output (None if it did not)."""
+    return getattr(x, "_tgis_xs", None)
+
+
+def with_xs(x: torch.Tensor, xs: torch.Tensor) -> torch.Tensor:
+    x._tgis_xs = xs
+    return x
+
+
+def xsum(x: torch.Tensor) -> torch.Tensor:
+    """Row sums of an f16 matrix for the lean GEMM (stand-alone producer; the fused producers are rmsnorm_residual and
+    the act=2 epilogue of gptq_gemm_lean)."""
+    assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 16 == 0
+    xs = torch.empty((x.shape[0], x.shape[1] // 16, 2), dtype=torch.float32, device=x.device)
+    _check(load_library().tgis_xsum_f16(_ptr(x), x.stride(0), _ptr(xs), xs.stride(0) // 2, x.shape[0], x.shape[1],
+                                        _stream()), "tgis_xsum_f16")
+    return xs
+
+
+def gptq_lean_ok(M: int, w: GptqWeight, act: int = 0) -> bool:
+    return bool(load_library().tgis_gptq_lean_ok(M, w.K, w.N, w.groups, int(w.perm is not None), act))
+
+
+def gptq_gemm_lean(x: torch.Tensor, xs: torch.Tensor, w: GptqWeight, ws: Workspace, bias=None, act: int = 0, out=None,
+                   want_xs: bool = False) -> torch.Tensor:
+    """tgis_gptq_gemm_f16_lean; act=2 with want_xs attaches the row sums of the activated output to it."""
+    assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == w.K
+    assert xs.dtype == torch.float32 and xs.is_contiguous() and xs.shape[0] == x.shape[0]
+    M = x.shape[0]
+    if out is None:
+        out = torch.empty((M, w.N // 2 if act == 2 else w.N), dtype=torch.float16, device=x.device)
+    xs_out = None
+    if want_xs and act == 2:
+        xs_out = torch.empty((M, w.N // 32, 2), dtype=torch.float32, device=x.device)
+    ws.ensure(w.workspace_bytes(M))
+    _check(
+        load_library().tgis_gptq_gemm_f16_lean(_ptr(x), x.stride(0), _ptr(xs), xs.stride(0) // 2, _ptr(w.image),
+                                               _ptr(bias), _ptr(out), out.stride(0), _ptr(xs_out), M, w.K, w.N,
+                                               w.groups, act, ws.ptr, ws.nbytes, _stream()),
+        "tgis_gptq_gemm_f16_lean")
+    return with_xs(out, xs_out) if xs_out is not None else out
+
+
+def gptq_gemm_partial_lean(x: torch.Tensor, xs: torch.Tensor, w: GptqWeight, bias=None) -> Partial:
+    """tgis_gptq_gemm_f16_partial_lean: the slab geometry is the one of gptq_gemm_partial (same plan)."""
+    assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] <= 32
+    lib = load_library()
+    M = x.shape[0]
+    plan = w.partial_plan.get(("lean", 0))
+    nbytes = plan[0] if plan else lib.tgis_gptq_gemm_partial_bytes(M, w.K, w.N)
+    slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    S, ld = _c_int(), _c_i64()
+    _check(
+        lib.tgis_gptq_gemm_f16_partial_lean(_ptr(x), x.stride(0), _ptr(xs), xs.stride(0) // 2, _ptr(w.image), M, w.K,
+                                            w.N, w.groups, _ptr(slabs), nbytes,
+                                            None if plan else ctypes.byref(S), None if plan else ctypes.byref(ld),
+                                            _stream()), "tgis_gptq_gemm_f16_partial_lean")
+    if plan is None:
+        plan = w.partial_plan[("lean", 0)] = (nbytes, S.value, ld.value)
+    return Partial(slabs, plan[1], plan[2], M, w.N, bias)
 
 
 def gptq_dequant(w: GptqWeight) -> torch.Tensor:
