@@ -115,6 +115,22 @@ int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void* prepared,
                                int64_t K, int64_t N, int64_t groups, int act, float* slabs, int64_t slabs_bytes,
                                int* num_slabs, int64_t* slab_ld, void* stream);
 
+/* ---- fused qkv projection + rotary embedding + cache write (decode, round 3) ------------------------------------------
+ * One launch for `qkv = query_key_value(x)`, `rotary_emb(q, k, cos, sin)` and `layer_past[slot] = (k, v)`
+ * (flash_llama_modeling.py:251-268,282) at decode sizes: the GEMM keeps the whole k range in a block (no split-K slabs)
+ * and its epilogue rounds the sum (+ bias) to f16, rotates q / k heads in fp32 (the arithmetic of tgis_rope_kv_write) and
+ * stores q to q_out[M, ldq] and k / v into the cache pages of slots[m] (page layouts of tgis_rope_kv_write).
+ * `prepared` is a SECOND image of the qkv weight made with flags = TGIS_GPTQ_ROPE_IMAGE(D, H + Hkv): inside each rotated
+ * head a 32-column tile holds 16 dims and their 16 rotation partners, so every wave owns complete rotation pairs.
+ * Full rotary span only (rot_dim == D).  tgis_gptq_rope_ok: 1 <= M <= 32, groups of 64 * 2^n rows, no act-order,
+ * D % 32 == 0. */
+#define TGIS_GPTQ_ROPE_IMAGE(D, rotated_heads) (2 | ((int)(D) << 8) | ((int)(rotated_heads) << 20))
+int tgis_gptq_rope_ok(int64_t M, int64_t K, int64_t groups, int act_order, int64_t D);
+int tgis_gptq_gemm_rope_f16(const void* x, int64_t ldx, const void* prepared, const void* bias, const int32_t* positions,
+                            const int32_t* slots, const void* cos, const void* sin, void* q_out, int64_t ldq,
+                            void* k_pool, void* v_pool, int64_t M, int64_t K, int64_t N, int64_t groups, int64_t H,
+                            int64_t Hkv, int64_t D, void* stream);
+
 /* ---- "lean" decode GEMM (round 3) -------------------------------------------------------------------------------
  * Same contract as tgis_gptq_gemm_f16 / tgis_gptq_gemm_f16_partial (the gemm_half_q_half call of
  * utils/gptq/exllamav2.py:139-144) for the shapes tgis_gptq_lean_ok() accepts — 1 <= M <= 32, group size 128, no
@@ -126,6 +142,9 @@ int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void* prepared,
  * xs: fp32 [M][ldxs][2] — per row and 16 consecutive columns of x the pair {sum of x[k] over k % 4 < 2, sum over
  * k % 4 >= 2} — written by the producer of x: tgis_rmsnorm_residual*_xs, the act = 2 epilogue of this GEMM (xs_out, the
  * sums of its own [M, N/2] output for the down projection) or tgis_xsum_f16 for any other f16 matrix. */
+/* 0, or the code a bounded in-kernel wait of the loader / consumer form left behind when it gave up (the launch then
+ * finished with garbage results instead of hanging); `reset` clears it.  Synchronises with the device. */
+int tgis_gptq_lean_status(int reset);
 int tgis_gptq_lean_ok(int64_t M, int64_t K, int64_t N, int64_t groups, int act_order, int act);
 int tgis_xsum_f16(const void* x, int64_t ldx, float* xs, int64_t ldxs, int64_t M, int64_t K, void* stream);
 int tgis_gptq_gemm_f16_lean(const void* x, int64_t ldx, const float* xs, int64_t ldxs, const void* prepared,

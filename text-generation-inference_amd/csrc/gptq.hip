@@ -32,8 +32,16 @@ using gptq::RS;
 
 // Column held by lane c (0..31) of tile nt.  flags bit 0 (gate/up interleave, for the fused SiLU*mul epilogue):
 // lanes 0-15 hold gate columns 16 nt + c, lanes 16-31 the matching up columns N/2 + 16 nt + (c - 16).
+// flags bit 1 (rope image of a fused qkv projection, for the rotary + cache-write epilogue; head size D in bits 8..19,
+// number of rotated heads H + Hkv in bits 20..31): a tile of a rotated head holds dims [16 t, 16 t + 16) in lanes 0-15 and
+// their rotation partners D/2 + [16 t, 16 t + 16) in lanes 16-31.
 __device__ __forceinline__ int64_t col_src(int64_t nt, int c, int64_t N, int flags) {
     if (flags & 1) return (c < 16) ? nt * 16 + c : (N >> 1) + nt * 16 + (c - 16);
+    if (flags & 2) {
+        const int D = (flags >> 8) & 0xFFF, nrot = (flags >> 20) & 0xFFF, per = D >> 5;
+        const int64_t head = nt / per, t = nt - head * per;
+        if (head < nrot) return head * D + ((c < 16) ? 16 * t + c : (D >> 1) + 16 * t + (c - 16));
+    }
     return nt * 32 + c;
 }
 
@@ -388,6 +396,12 @@ extern "C" int tgis_gptq_prepare(const int32_t* qweight, const int32_t* qzeros, 
                                  int64_t groups, int flags, void* prepared, void* stream) {
     TGIS_CHECK_ARG(qweight && qzeros && scales && prepared, "tgis_gptq_prepare: null tensor");
     TGIS_CHECK_ARG(!(flags & 1) || (N % 32 == 0), "tgis_gptq_prepare: gate/up interleave needs N/2 %% 16 == 0");
+    if (flags & 2) {
+        const int D = (flags >> 8) & 0xFFF, nrot = (flags >> 20) & 0xFFF;
+        TGIS_CHECK_ARG(!(flags & 1) && D >= 32 && D % 32 == 0 && nrot >= 1 && (int64_t)nrot * D <= N && N % D == 0,
+                       "tgis_gptq_prepare: rope image needs head size %% 32 == 0 and rotated heads within N (D=%d, heads=%d)",
+                       D, nrot);
+    }
     TGIS_CHECK_ARG(K > 0 && N > 0 && K % 32 == 0 && N % 32 == 0,
                    "tgis_gptq_prepare: K (%ld) and N (%ld) must be positive multiples of 32", (long)K, (long)N);
     TGIS_CHECK_ARG(groups > 0 && K % groups == 0, "tgis_gptq_prepare: K %% groups != 0");
@@ -500,6 +514,10 @@ static int launch_tall(const void* x, int64_t ldx, const void* prepared, const v
     a.partial = partial;
     a.spg_shift = 30;
     a.err = nullptr;
+    a.positions = a.slots = nullptr;
+    a.cosb = a.sinb = nullptr;
+    a.kpool = a.vpool = nullptr;
+    a.rH = a.rHkv = a.rD = 0;
     if (groups > 1)
         for (a.spg_shift = 0; (1 << a.spg_shift) < spg; ++a.spg_shift) {}
     const int BM = 32 * tp.BMR;
@@ -561,15 +579,22 @@ static int launch_one(dim3 grid, size_t lds, hipStream_t st, const GemmArgs& a) 
 }
 template <int TN, int WK, int ACT, bool G64, bool PERM>
 static int launch_variant(int mr, dim3 grid, size_t lds, hipStream_t st, const GemmArgs& a) {
-    if constexpr (WK == 2) {  // 64-row passes exist for two-k-part blocks only (LDS)
+    if constexpr (WK == 2 && ACT != 3) {  // 64-row passes exist for two-k-part blocks only (LDS); not for the rope epilogue
         if (mr == 2) return launch_one<TN, WK, ACT, G64, PERM, 2>(grid, lds, st, a);
     }
     return launch_one<TN, WK, ACT, G64, PERM, 1>(grid, lds, st, a);
 }
 
+struct RopeEpi {
+    const int32_t *positions, *slots;
+    const f16 *cosb, *sinb;
+    f16 *kpool, *vpool;
+    int H, Hkv, D;
+};
+
 static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const void* bias, const int32_t* perm,
                        void* out, int64_t ldo, int64_t M, int64_t K, int64_t N, int64_t groups, int act, float* slabs,
-                       int partial, const GemmPlan& pl, hipStream_t st) {
+                       int partial, const GemmPlan& pl, hipStream_t st, const RopeEpi* rope = nullptr) {
     PrepLayout p = prep_layout(K, N, groups);
     const int64_t mslabs = cdiv64(M, 32 * pl.MR);  // passes over the weights
     const int64_t gs = K / groups;
@@ -597,6 +622,21 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
     a.partial = partial;
     a.spg_shift = 30;
     a.err = nullptr;
+    a.positions = a.slots = nullptr;
+    a.cosb = a.sinb = nullptr;
+    a.kpool = a.vpool = nullptr;
+    a.rH = a.rHkv = a.rD = 0;
+    if (rope) {
+        a.positions = rope->positions;
+        a.slots = rope->slots;
+        a.cosb = rope->cosb;
+        a.sinb = rope->sinb;
+        a.kpool = rope->kpool;
+        a.vpool = rope->vpool;
+        a.rH = rope->H;
+        a.rHkv = rope->Hkv;
+        a.rD = rope->D;
+    }
     if (groups > 1 && group64)
         for (a.spg_shift = 0; (1 << a.spg_shift) < spg; ++a.spg_shift) {}
     dim3 grid((unsigned)cdiv64(p.NT, pl.TN), (unsigned)pl.S, (unsigned)mslabs);
@@ -622,6 +662,11 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
         else                                             \
             TGIS_LAUNCH_GEMM(2, 2, A, G, P);             \
     } while (0)
+    if (act == 3) {  // rope epilogue: 64 * 2^n groups, no act-order (checked by the caller)
+        TGIS_LAUNCH_GEMM_W(3, true, false);
+        TGIS_CHECK_LAUNCH();
+        return TGIS_OK;
+    }
     const int variant = (act == 1 ? 4 : act == 2 ? 8 : 0) | (group64 ? 2 : 0) | (perm ? 1 : 0);
     switch (variant) {
         case 8: TGIS_LAUNCH_GEMM_W(2, false, false); break;
@@ -687,6 +732,32 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
     TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
     return launch_gptq(x, ldx, prepared, bias, perm, out, ldo, M, K, N, groups, act,
                        (float*)((uint8_t*)workspace + 4096), 0, pl, st);
+}
+
+// ---- qkv projection with the rotary embedding and the cache write in its epilogue ------------------------------------
+extern "C" int tgis_gptq_rope_ok(int64_t M, int64_t K, int64_t groups, int act_order, int64_t D) {
+    if (M < 1 || M > 32 || act_order || groups <= 0 || K % groups || D < 32 || D % 32) return 0;
+    const int64_t gs = K / groups, spg = gs / 64;
+    return (groups == 1 || (gs % 64 == 0 && (spg & (spg - 1)) == 0)) ? 1 : 0;
+}
+
+extern "C" int tgis_gptq_gemm_rope_f16(const void* x, int64_t ldx, const void* prepared, const void* bias,
+                                       const int32_t* positions, const int32_t* slots, const void* cos, const void* sin,
+                                       void* q_out, int64_t ldq, void* k_pool, void* v_pool, int64_t M, int64_t K, int64_t N,
+                                       int64_t groups, int64_t H, int64_t Hkv, int64_t D, void* stream) {
+    int rc = check_gemm_args(x, ldx, prepared, M, K, N, groups, 0);
+    if (rc != TGIS_OK) return rc;
+    TGIS_CHECK_ARG(positions && slots && cos && sin && q_out && k_pool && v_pool, "tgis_gptq_gemm_rope_f16: null tensor");
+    TGIS_CHECK_ARG(tgis_gptq_rope_ok(M, K, groups, 0, D), "tgis_gptq_gemm_rope_f16: needs 1 <= M <= 32, groups of 64 * 2^n "
+                   "rows and a head size that is a multiple of 32 (M=%ld K=%ld groups=%ld D=%ld)", (long)M, (long)K,
+                   (long)groups, (long)D);
+    TGIS_CHECK_ARG(H >= 1 && Hkv >= 1 && (H + 2 * Hkv) * D == N && ldq >= H * D,
+                   "tgis_gptq_gemm_rope_f16: N must be (H + 2 Hkv) * D and q rows must hold H * D elements");
+    GemmPlan pl = plan_gemm(K, N, 2, M);  // as the SiLU epilogue: the whole k range in one block (S == 1)
+    RopeEpi rope{positions, slots, (const f16*)cos, (const f16*)sin, (f16*)k_pool, (f16*)v_pool, (int)H, (int)Hkv, (int)D};
+    hipStream_t st = (hipStream_t)stream;
+    TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
+    return launch_gptq(x, ldx, prepared, bias, nullptr, q_out, ldq, M, K, N, groups, 3, nullptr, 0, pl, st, &rope);
 }
 
 extern "C" int64_t tgis_gptq_gemm_partial_bytes(int64_t M, int64_t K, int64_t N) {

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <type_traits>
 #include "common.h"
+#include "kv_layout.h"
 
 namespace gptq {
 
@@ -76,6 +77,14 @@ struct GemmArgs {
     int partial;   // 1: always leave fp32 slabs (deferred reduce), never write `out`
     int spg_shift; // GROUP64: log2(k64-steps per group) (30 when there is a single group)
     unsigned* err; // decode tail: word that receives a code when a bounded spin gives up (nullptr otherwise)
+    // ACT == 3 (rope image): the epilogue rotates q / k heads and writes k / v into their cache pages; `out` is the q tensor
+    const int32_t* positions;  // [M]
+    const int32_t* slots;      // [M] page * 32 + token
+    const f16* cosb;           // [max_pos][rD / 2]
+    const f16* sinb;
+    f16* kpool;                // [pages][rHkv][32 * rD] in the K page layout of kv_layout.h
+    f16* vpool;
+    int rH, rHkv, rD;
 };
 constexpr unsigned TAIL_SPIN_LIMIT = 1u << 24;
 
@@ -144,7 +153,8 @@ template <int TN, int WK, int ACT, bool GROUP64, bool PERM, int MR, bool TAIL, i
 __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg, const int split, const int mslab,
                                                unsigned char* smem, const int ub_base, WeightRing<RING>& ring) {
     static_assert(MR == 1 || WK == 2, "64-row passes need the LDS of two k-parts");
-    static_assert(!TAIL || (MR == 1 && !PERM && ACT != 1), "the decode tail runs 32-row, un-permuted units");
+    static_assert(!TAIL || (MR == 1 && !PERM && ACT != 1 && ACT != 3), "the decode tail runs 32-row, un-permuted units");
+    static_assert(ACT != 3 || (MR == 1 && !PERM), "the rope epilogue is a decode form (<= 32 rows, no act-order)");
     static_assert(RING == 4 || RING == 8, "one or two chunks of weights in flight");
     static_assert(MODE == UNIT_FULL || GROUP64, "a pre-filled ring carries the scales of GROUP64 images");
     constexpr int NWAVES = TN * WK;
@@ -201,6 +211,18 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
 #pragma unroll
         for (int s = 0; s < RING; ++s) wq[s] = w_at(s);
         return;
+    }
+
+    // ACT 3: cache slot and rotary position of the rows this wave will finish (see the distributed epilogue)
+    int32_t rpos[ACT == 3 ? 16 / WK : 1], rslot[ACT == 3 ? 16 / WK : 1];
+    if (ACT == 3) {
+#pragma unroll
+        for (int j = 0; j < 16 / WK; ++j) {
+            const int r = wk * (16 / WK) + j;
+            const int m = min((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), mrows - 1);
+            rpos[j] = a.positions[m0 + m];
+            rslot[j] = a.slots[m0 + m];
+        }
     }
 
     // ---- x staging: local thread t handles rows (t / 32) + RSTEP j, 16-byte column piece (t & 31) ----
@@ -449,12 +471,154 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
         }
     }
     TRACE(9);
+    // Non-TAIL units finish DISTRIBUTED (below): wave (wn, wk) ends up with accumulator registers [wk NR, (wk + 1) NR) of
+    // its tile, i.e. NR of the 16 row groups.  ACT 3: it asks for those rows' cos / sin entries now (the positions were
+    // loaded at entry), so that the round trip runs under the k-part exchange.
+    constexpr int NR = 16 / WK;
+    f16 rcos[MR == 1 ? NR : 1], rsin[MR == 1 ? NR : 1];
+    if (ACT == 3) {
+        const int per = a.rD >> 5;
+        const int tt = nt - (nt / per) * per;
+        const int dr = 16 * tt + (lane & 15);
+        const bool roth = nt / per < a.rH + a.rHkv;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            rcos[j] = roth ? a.cosb[(int64_t)rpos[j] * (a.rD >> 1) + dr] : (f16)1.f;
+            rsin[j] = roth ? a.sinb[(int64_t)rpos[j] * (a.rD >> 1) + dr] : (f16)0.f;
+        }
+    }
     unit_barrier();  // every k-part is done with its x buffers: the reduction below reuses them
 
     f32x16 acc[MR];
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) acc[mr] = NACC == 2 ? accs[mr][0] + accs[mr][1] : accs[mr][0];
-    // ---- sum the WK k-parts through LDS (fixed order => deterministic) --------------------------------
+    // ---- stand-alone kernel: distributed finish ---------------------------------------------------------------------
+    // Every wave (k-part 0 included) leaves its partial sums in LDS; wave (wn, wk) then sums the WK k-parts of registers
+    // [wk NR, (wk + 1) NR) of tile wn in the fixed order 0..WK-1 (bit-identical to the reducer-wave form) and runs the
+    // epilogue for those rows only: the loads, the arithmetic and the scattered stores of the tail are spread over all
+    // waves of the block instead of a quarter of them.
+    if (!TAIL && WK > 1) {
+        float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][MR][64 lanes][16]; the x buffers are dead now
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            float* dst = red + ((((wk * TN + wn) * MR + mr) * 64 + lane) << 4);
+#pragma unroll
+            for (int r = 0; r < 16; r += 4)
+                *reinterpret_cast<f32x4*>(dst + r) = f32x4{acc[mr][r], acc[mr][r + 1], acc[mr][r + 2], acc[mr][r + 3]};
+        }
+        unit_barrier();
+        TRACE(11);
+        if (nt_raw >= a.NT) return;
+        float fin[MR][NR];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) fin[mr][j] = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < WK; ++k2) {
+                const float* src = red + ((((k2 * TN + wn) * MR + mr) * 64 + lane) << 4) + wk * NR;
+#pragma unroll
+                for (int j = 0; j < NR; j += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(src + j);
+                    if (k2 == 0) {
+                        fin[mr][j] = t[0], fin[mr][j + 1] = t[1], fin[mr][j + 2] = t[2], fin[mr][j + 3] = t[3];
+                    } else {
+                        fin[mr][j] += t[0], fin[mr][j + 1] += t[1], fin[mr][j + 2] += t[2], fin[mr][j + 3] += t[3];
+                    }
+                }
+            }
+        }
+        TRACE(12);
+        const int c = lane & 31;
+        auto row_of = [&](int j) {  // row (within the 32-row block) of finished register j
+            const int r = wk * NR + j;
+            return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        };
+        if (ACT == 3) {
+            // Rope image (col_src flags bit 1): a tile of a q or k head holds dims [16 t, 16 t + 16) in lanes c < 16 and
+            // their rotation partners rD/2 + [16 t, 16 t + 16) in lanes c + 16; v heads keep 32 consecutive dims.  The sum
+            // (+ bias) is rounded to f16 first, then rotated in fp32 — the arithmetic of rope_kv_kernel on the reduced
+            // activation (rotary_emb.apply_rotary, utils/layers.py:466-472) — and q goes to `out`, k / v straight into
+            // their cache pages (flash_llama_modeling.py:268,282).  Host guarantees S == 1.
+            const int per = a.rD >> 5;
+            const int head = nt / per, tt = nt - head * per;
+            const bool roth = head < a.rH + a.rHkv;
+            const int d = roth ? ((c < 16) ? 16 * tt + c : (a.rD >> 1) + 16 * tt + (c - 16)) : 32 * tt + c;
+            const int col = head * a.rD + d;
+            const float bv = a.bias ? (float)a.bias[col] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int m = row_of(j);
+                const float mine = (float)(f16)(fin[0][j] + bv);
+                float o = mine;
+                if (roth) {
+                    const float other = __shfl_xor(mine, 16, 64);
+                    const float cf = (float)rcos[j], sf = (float)rsin[j];
+                    o = (c < 16) ? mine * cf - other * sf : other * sf + mine * cf;
+                }
+                const f16 oh = (f16)o;
+                if (m < mrows) {
+                    if (head < a.rH) {
+                        a.out[(int64_t)(m0 + m) * a.ldo + col] = oh;
+                    } else {
+                        const int page = rslot[j] >> 5, tok = rslot[j] & 31;
+                        if (roth)
+                            a.kpool[((int64_t)page * a.rHkv + (head - a.rH)) * 32 * a.rD + k_off(tok, d, a.rD)] = oh;
+                        else
+                            a.vpool[((int64_t)page * a.rHkv + (head - a.rH - a.rHkv)) * 32 * a.rD + (int64_t)d * 32 +
+                                    v_col(tok)] = oh;
+                    }
+                }
+            }
+            return;
+        }
+        const int n = nt * 32 + c;
+        if (ACT == 2) {
+            // interleaved gate/up pairs (col_src flags bit 0): lanes c < 16 hold gate column j2 = 16 nt + c, lanes c + 16
+            // the matching up column.  out[m][j2] = f16(f16(silu(f16 gate)) * f16 up), the rounding sequence of the
+            // reference's eager ops (flash_llama_modeling.py:332-335).  Host guarantees S == 1.
+            const int half = a.N >> 1;
+            const int j2 = nt * 16 + (c & 15);
+            const int nsrc = (c < 16) ? j2 : half + j2;
+            const float bv = (a.bias && j2 < half) ? (float)a.bias[nsrc] : 0.f;
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const float mine = (float)(f16)(fin[mr][j] + bv);
+                    const float other = __shfl_xor(mine, 16, 64);
+                    const int m = mr * 32 + row_of(j);
+                    if (c < 16 && j2 < half && m < mrows) {
+                        float sl = mine / (1.f + __expf(-mine));
+                        a.out[(int64_t)(m0 + m) * a.ldo + j2] = (f16)((float)(f16)sl * other);
+                    }
+                }
+            return;
+        }
+        if (a.S == 1 && !a.partial) {
+            const float bv = (a.bias && n < a.N) ? (float)a.bias[n] : 0.f;
+            if (n < a.N) {
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        const int m = mr * 32 + row_of(j);
+                        if (m < mrows) a.out[(int64_t)(m0 + m) * a.ldo + n] = (f16)(fin[mr][j] + bv);
+                    }
+            }
+        } else {
+            // slabs are indexed in 32-row units: this pass owns units mslab*MR .. mslab*MR + MR-1
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+                float* sl = a.slabs + ((int64_t)((mslab * MR + mr) * a.S + split) * 32) * (a.NT * 32) + n;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) sl[(int64_t)row_of(j) * (a.NT * 32)] = fin[mr][j];
+            }
+        }
+        return;
+    }
+
+    // ---- decode tail: sum the WK k-parts through LDS in reducer waves (fixed order => deterministic) -----------------
     if (WK > 1) {
         float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][MR][64 lanes][16]; the x buffers are dead now
         if (wk > 0) {

@@ -4,7 +4,7 @@
 // group-size-128 images without act-order; everything else keeps gptq_gemm_kernel (gptq.hip).
 #include <stdlib.h>
 #include "common.h"
-#include "gptq_lean_body.h"
+#include "gptq_ld_body.h"
 
 namespace {
 
@@ -17,6 +17,15 @@ template <int TN, int WK, int ACT, int RING>
 __global__ __launch_bounds__(64 * TN * WK) void gptq_lean_kernel(LeanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     gptq::gptq_lean_unit<TN, WK, ACT, RING>(a, blockIdx.x, blockIdx.y, smem);
+}
+
+__device__ unsigned g_ld_err;  // code left by a bounded spin of the loader / consumer kernel that gave up (0: never)
+
+template <int TN, int WK, int ACT, int D>
+__global__ __launch_bounds__(64 * (TN * WK + 1)) void gptq_ld_kernel(LeanArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    a.g.err = &g_ld_err;
+    gptq::gptq_ld_unit<TN, WK, ACT, D>(a, blockIdx.x, blockIdx.y, smem);
 }
 
 // {XA, XB} per row and 16 columns of an f16 matrix: XA = sum of x[k] over k % 4 < 2, XB over k % 4 >= 2 (fp32, fixed
@@ -50,6 +59,42 @@ int launch_one(dim3 grid, hipStream_t st, const LeanArgs& a) {
     }
     hipLaunchKernelGGL((gptq_lean_kernel<TN, WK, ACT, RING>), grid, dim3(64 * TN * WK), gptq::lean_lds_bytes(WK), st, a);
     return TGIS_OK;
+}
+
+// 0: register-ring kernel, 1: loader / consumer kernel (LDS-DMA ring)
+int use_ld() {
+    static const int v = getenv("TGIS_LEAN_LD") ? atoi(getenv("TGIS_LEAN_LD")) : 1;
+    return v;
+}
+int ld_depth() {
+    static const int v = getenv("TGIS_LEAN_D") ? atoi(getenv("TGIS_LEAN_D")) : 4;
+    return v == 8 ? 8 : 4;
+}
+
+template <int TN, int WK, int ACT, int D>
+int launch_ld_one(dim3 grid, hipStream_t st, const LeanArgs& a) {
+    constexpr int lds = gptq::ld_lds_bytes(TN * WK, WK, D);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_ld_kernel<TN, WK, ACT, D>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gptq_ld_kernel<TN, WK, ACT, D>), grid, dim3(64 * (TN * WK + 1)), lds, st, a);
+    return TGIS_OK;
+}
+
+template <int ACT>
+int launch_ld(const GemmPlan& pl, dim3 grid, hipStream_t st, const LeanArgs& a) {
+    const bool deep = ld_depth() == 8;
+    switch (pl.TN * 10 + pl.WK) {
+        case 34: return launch_ld_one<3, 4, ACT, 4>(grid, st, a);
+        case 42: return deep ? launch_ld_one<4, 2, ACT, 8>(grid, st, a) : launch_ld_one<4, 2, ACT, 4>(grid, st, a);
+        case 32: return deep ? launch_ld_one<3, 2, ACT, 8>(grid, st, a) : launch_ld_one<3, 2, ACT, 4>(grid, st, a);
+        case 24: return deep ? launch_ld_one<2, 4, ACT, 8>(grid, st, a) : launch_ld_one<2, 4, ACT, 4>(grid, st, a);
+        default: return deep ? launch_ld_one<2, 2, ACT, 8>(grid, st, a) : launch_ld_one<2, 2, ACT, 4>(grid, st, a);
+    }
 }
 
 template <int ACT, int RING>
@@ -94,8 +139,21 @@ int launch_lean(const void* x, int64_t ldx, const float* xs, int64_t ldxs, const
     la.xs = xs;
     la.ldxs = ldxs;
     la.xs_out = xs_out;
-    dim3 grid((unsigned)cdiv64(p.NT, pl.TN), (unsigned)pl.S, 1);
+    static const int dbg = getenv("TGIS_LEAN_DBG") ? atoi(getenv("TGIS_LEAN_DBG")) : 0;
+    la.dbg = dbg;
     int rc;
+    if (use_ld()) {
+        // one wave of the workgroup is the loader: at most 15 consumers (4 x 4 plans run as 3 x 4)
+        GemmPlan lp = pl;
+        if (lp.TN * lp.WK > 15) lp.TN = 3;
+        dim3 lgrid((unsigned)cdiv64(p.NT, lp.TN), (unsigned)lp.S, 1);
+        rc = act == 2 ? launch_ld<2>(lp, lgrid, st, la) : launch_ld<0>(lp, lgrid, st, la);
+        if (rc != TGIS_OK) return rc;
+        TGIS_CHECK_LAUNCH();
+        if (!partial && pl.S > 1) return gptq::reduce_slabs(slabs, a.bias, a.out, a.ldo, a.M, a.N, (int)p.NT * 32, a.S, st);
+        return TGIS_OK;
+    }
+    dim3 grid((unsigned)cdiv64(p.NT, pl.TN), (unsigned)pl.S, 1);
     if (ring_depth() == 8)
         rc = act == 2 ? launch_tw<2, 8>(pl, grid, st, la) : launch_tw<0, 8>(pl, grid, st, la);
     else
@@ -119,6 +177,24 @@ int check_lean_args(const void* x, int64_t ldx, const float* xs, int64_t ldxs, c
 }
 
 }  // namespace
+
+#ifdef TGIS_TRACE
+extern "C" int tgis_debug_set_trace_lean(void* ptr) {
+    long long* p = (long long*)ptr;
+    TGIS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gptq::g_trace), &p, sizeof(p)));
+    return TGIS_OK;
+}
+#endif
+
+extern "C" int tgis_gptq_lean_status(int reset) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ld_err), sizeof(v)) != hipSuccess) return -1;
+    if (reset && v) {
+        const unsigned z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ld_err), &z, sizeof(z));
+    }
+    return (int)v;
+}
 
 extern "C" int tgis_gptq_lean_ok(int64_t M, int64_t K, int64_t N, int64_t groups, int act_order, int act) {
     return gptq::lean_ok(M, K, N, groups, act_order != 0, act) ? 1 : 0;

@@ -29,6 +29,8 @@ struct LeanArgs {
     const float* xs;   // [M][ldxs][2] fp32: {XA, XB} of x per row and 16 k
     int64_t ldxs;      // 16-k blocks per row of xs (>= K / 16)
     float* xs_out;     // act == 2: the same sums of the activated output [M][N/32][2] (nullptr: not wanted)
+    int dbg;           // measurement switches (TGIS_LEAN_DBG, wrong results): 1 no x loads, 2 no row-sum loads, 4 no scale
+                       // loads, 8 consumers do not wait for / read the ring, 16 the loader issues nothing
 };
 
 constexpr int LEAN_XBYTES = 2 * 32 * RS * (int)sizeof(f16);  // x chunk double buffer of one k-part
@@ -65,6 +67,61 @@ __device__ __forceinline__ f16x8 unpack8(uint32_t q, uint32_t EXA, uint32_t EXB,
     const uint32_t q2 = q >> 8;
     u32x4 p = {(q & M0) | EXA, (q & M1) | EXB, (q2 & M0) | EXA, (q2 & M1) | EXB};
     return __builtin_bit_cast(f16x8, p);
+}
+
+// Epilogue shared by the lean units: lane holds out[m = (r&3) + 8 (r>>2) + 4 (lane>>5)][n = nt*32 + (lane&31)].
+template <int ACT>
+__device__ __forceinline__ void lean_epilogue(const LeanArgs& la, const f32x16& acc, const int nt_raw, const int nt,
+                                              const int split, const int mrows, const int lane) {
+    const GemmArgs& a = la.g;
+    if (nt_raw >= a.NT) return;
+    const int n = nt * 32 + (lane & 31);
+    if (ACT == 2) {
+        // interleaved gate/up image: lanes c < 16 hold gate column j = 16 nt + c, lanes c + 16 the matching up column;
+        // out[m][j] = f16(f16(silu(f16 gate)) * f16 up) (flash_llama_modeling.py:332-335).  Host guarantees S == 1.
+        const int c = lane & 31;
+        const int half = a.N >> 1;
+        const int j = nt * 16 + (c & 15);
+        const int nsrc = (c < 16) ? j : half + j;
+        const float bv = (a.bias && j < half) ? (float)a.bias[nsrc] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float mine = (float)(f16)(acc[r] + bv);
+            const float other = __shfl_xor(mine, 16, 64);
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float sl = mine / (1.f + __expf(-mine));
+            const f16 o = (f16)((float)(f16)sl * other);
+            if (c < 16 && j < half && m < mrows) a.out[(int64_t)m * a.ldo + j] = o;
+            if (la.xs_out) {
+                // row sums of this tile's 16 activated columns for the consumer GEMM: lanes c % 4 < 2 carry low-nibble
+                // rows of its image, c % 4 >= 2 high-nibble rows.  Pairs, then the four quads of the 16-lane row:
+                // lanes 12/13 end with XA, lanes 14/15 with XB (fixed order).
+                float v = (c < 16 && j < half) ? (float)o : 0.f;
+                v += dpp_quad_swap1(v);
+                v += dpp_row_shr(v, 4);
+                v += dpp_row_shr(v, 8);
+                if ((c == 12 || c == 14) && m < mrows) la.xs_out[((int64_t)m * a.NT + nt) * 2 + ((c >> 1) & 1)] = v;
+            }
+        }
+        return;
+    }
+    if (a.S == 1 && !a.partial) {
+        const float bv = (a.bias && n < a.N) ? (float)a.bias[n] : 0.f;
+        if (n < a.N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < mrows) a.out[(int64_t)m * a.ldo + n] = (f16)(acc[r] + bv);
+            }
+        }
+    } else {
+        float* sl = a.slabs + ((int64_t)split * 32) * (a.NT * 32) + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            sl[(int64_t)m * (a.NT * 32)] = acc[r];
+        }
+    }
 }
 
 template <int TN, int WK, int ACT, int RING>
@@ -123,7 +180,7 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
 #pragma unroll
     for (int j = 0; j < NJ; ++j) rowoff[j] = (uint32_t)(min(srow + RSTEP * j, mrows - 1) * (int)a.ldx * 2);
     // quarter-task q: row q >> 3, group (q >> 2) & 1 of the chunk, quarter q & 3 = two of the group's eight 16-k blocks
-    f32x4 xq[NQ];
+    f32x4 xq[NQ] = {};
     uint32_t xsrow[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -140,18 +197,21 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
         const char* sb = reinterpret_cast<const char*>(la.xs);
         PIN_SGPR(sb);
         const int kb0 = (k0 + chunk * KC) >> 4;
+#if !defined(LEAN_ABL) || !(LEAN_ABL & 2)
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int q = ltid + i * GT;
             const int kb = min(kb0 + ((q >> 2) & 1) * 8 + (q & 3) * 2, kb_last);
             xq[i] = *(const GLOBAL_AS f32x4*)(sb + ((size_t)xsrow[i] + (uint32_t)kb) * 8);
         }
+#endif
     };
     auto stage_store = [&](int buf) {
         f16* dst = xs + buf * (32 * RS) + srow * RS + scol;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
             if (NJ * RSTEP == 32 || srow + RSTEP * j < 32) st16(dst + j * RSTEP * RS, xg[j]);
+#if !defined(LEAN_ABL) || !(LEAN_ABL & 2)
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int q = ltid + i * GT;
@@ -167,6 +227,7 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
             if ((q & 3) == 0 && (NQ * GT == 256 || q < 256))
                 st16(aps + ((buf * 2 + ((q >> 2) & 1)) * 32 + (q >> 3)) * 16, ap);
         }
+#endif
     };
 
     uint32_t EXA = 0x64006400u, EXB = 0x54005400u, M0r = 0x000F000Fu, M1r = 0x00F000F0u;
@@ -218,8 +279,12 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
             const f16 bA = szh[1] * (f16)-16.f;        // -16 (1024 + z + 1), exact
             const f16 bB = bA + (f16)15360.f;           // -16 (64 + z + 1), exact
             const f16x8 bp = {bA, bA, bA, bB, bB, bB, (f16)0.f, (f16)0.f};
+#if defined(LEAN_ABL) && (LEAN_ABL & 1)
+            f32x16 g = acc;
+#else
             const f16x8 ap = ld16<f16x8>(apbuf + (lane < 32 ? gi * (32 * 16) : 0));
             f32x16 g = mfma32(ap, bp, zero16);
+#endif
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int s4 = gi * 2 + s2;
@@ -237,9 +302,14 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
 #pragma unroll
                 for (int i = 0; i < 4; ++i) g = mfma32(ld16<f16x8>(xk + i * 8), b[i], g);
             }
+#if defined(LEAN_ABL) && (LEAN_ABL & 1)
+            acc = g;
+            acc[0] += (float)szh[0] + (float)bp[0];
+#else
             const float sc = (float)szh[0];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(sc, g[r], acc[r]);
+#endif
         }
         if (REFILL) {
 #pragma unroll
@@ -303,55 +373,7 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
         }
     }
 
-    // ---- epilogue: lane holds out[m = (r&3) + 8 (r>>2) + 4 (lane>>5)][n = nt*32 + (lane&31)] ---------------------------
-    if (nt_raw >= a.NT) return;
-    const int n = nt * 32 + (lane & 31);
-    if (ACT == 2) {
-        // interleaved gate/up image: lanes c < 16 hold gate column j = 16 nt + c, lanes c + 16 the matching up column;
-        // out[m][j] = f16(f16(silu(f16 gate)) * f16 up) (flash_llama_modeling.py:332-335).  Host guarantees S == 1.
-        const int c = lane & 31;
-        const int half = a.N >> 1;
-        const int j = nt * 16 + (c & 15);
-        const int nsrc = (c < 16) ? j : half + j;
-        const float bv = (a.bias && j < half) ? (float)a.bias[nsrc] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float mine = (float)(f16)(acc[r] + bv);
-            const float other = __shfl_xor(mine, 16, 64);
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const float sl = mine / (1.f + __expf(-mine));
-            const f16 o = (f16)((float)(f16)sl * other);
-            if (c < 16 && j < half && m < mrows) a.out[(int64_t)m * a.ldo + j] = o;
-            if (la.xs_out) {
-                // row sums of this tile's 16 activated columns for the consumer GEMM: lanes c % 4 < 2 carry low-nibble
-                // rows of its image, c % 4 >= 2 high-nibble rows.  Pairs, then the four quads of the 16-lane row:
-                // lanes 12/13 end with XA, lanes 14/15 with XB (fixed order).
-                float v = (c < 16 && j < half) ? (float)o : 0.f;
-                v += dpp_quad_swap1(v);
-                v += dpp_row_shr(v, 4);
-                v += dpp_row_shr(v, 8);
-                if ((c == 12 || c == 14) && m < mrows) la.xs_out[((int64_t)m * a.NT + nt) * 2 + ((c >> 1) & 1)] = v;
-            }
-        }
-        return;
-    }
-    if (a.S == 1 && !a.partial) {
-        const float bv = (a.bias && n < a.N) ? (float)a.bias[n] : 0.f;
-        if (n < a.N) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < mrows) a.out[(int64_t)m * a.ldo + n] = (f16)(acc[r] + bv);
-            }
-        }
-    } else {
-        float* sl = a.slabs + ((int64_t)split * 32) * (a.NT * 32) + n;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            sl[(int64_t)m * (a.NT * 32)] = acc[r];
-        }
-    }
+    lean_epilogue<ACT>(la, acc, nt_raw, nt, split, mrows, lane);
 }
 
 // Whether the lean kernel covers this GEMM (otherwise the caller keeps gptq_gemm_kernel).

@@ -137,13 +137,23 @@ class FlashLlamaAttention:
             bias=config.attention_bias)
         self.o_proj = TensorParallelRowLinear.load(config, prefix=f"{prefix}.o_proj", weights=weights,
                                                    bias=config.attention_bias)
+        # int4 qkv: decode steps of up to 32 rows rotate q / k and write the cache in the GEMM epilogue
+        if hasattr(self.query_key_value.linear, "rope_heads"):
+            self.query_key_value.linear.rope_heads = (self.num_heads, self.num_key_value_heads, self.head_size)
 
     def project_qkv(self, hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id: int, kv: KVArgs):
         """qkv GEMM, rotation of q and k in place, k and v scattered to their page slots (reference :251-268,282)."""
         H, Hkv, D = self.num_heads, self.num_key_value_heads, self.head_size
+        k_pool, v_pool = kv.cache.k_pool(layer_id), kv.cache.v_pool(layer_id)
+        lin = self.query_key_value.linear
+        rope_w = getattr(lin, "rope_handle", None)
+        if (rope_w is not None and kv.slots is not None and not kv.fresh_prefill and kv.max_q_len == 1
+                and hidden_states.shape[0] <= 32 and cos.shape[1] * 2 == D):
+            # one launch: GEMM + rotary embedding + cache write (native.gptq_gemm_rope)
+            return native.gptq_gemm_rope(hidden_states, rope_w, lin.bias, cos, sin, position_ids, kv.slots, k_pool, v_pool,
+                                         H, Hkv, D)
         # [T, (H + 2 Hkv) D]; at decode sizes the split-K sum of the GPTQ GEMM is finished inside the rope kernel
         qkv = self.query_key_value(hidden_states, partial=True)
-        k_pool, v_pool = kv.cache.k_pool(layer_id), kv.cache.v_pool(layer_id)
         if kv.fresh_prefill and not isinstance(qkv, native.Partial):
             return native.rope_kv_write_prefill(qkv, cos, sin, position_ids, cu_seqlens_q, kv.block_tables, k_pool, v_pool,
                                                 kv.max_q_len, H, Hkv, D, D)

@@ -62,7 +62,11 @@ SIGNATURES = {
     "tgis_gptq_gemm_f16_partial": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_i64,
                                             ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64), _vp]),
     "tgis_gptq_dequant_f16": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp]),
+    "tgis_gptq_rope_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_int, _c_i64]),
+    "tgis_gptq_gemm_rope_f16": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _c_i64,
+                                         _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp]),
     "tgis_gptq_lean_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int]),
+    "tgis_gptq_lean_status": (_c_int, [_c_int]),
     "tgis_xsum_f16": (_c_int, [_vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64, _vp]),
     "tgis_gptq_gemm_f16_lean": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64,
                                          _c_i64, _c_int, _vp, _c_i64, _vp]),
@@ -221,8 +225,13 @@ class GptqWeight:
     """Prepared (repacked) GPTQ matrix; owner of the device image. Mirrors the q_handle of
     Ex4bitLinearV2.post_init (utils/gptq/exllamav2.py:124-137)."""
 
-    def __init__(self, qweight, qzeros, scales, g_idx, bits: int, groupsize: int, gate_up: bool = False):
+    def __init__(self, qweight, qzeros, scales, g_idx, bits: int, groupsize: int, gate_up: bool = False,
+                 rope: Optional[tuple] = None):
+        """rope = (D, rotated heads): the image of a fused qkv projection for gptq_gemm_rope (TGIS_GPTQ_ROPE_IMAGE)."""
         self.flags = 1 if gate_up else 0
+        if rope is not None:
+            assert not gate_up
+            self.flags = 2 | (int(rope[0]) << 8) | (int(rope[1]) << 20)
         self.partial_plan = {}  # pass count -> (slab bytes, S, ld) of the deferred-reduce form, filled on first use
         if bits != 4:
             raise TgisHipError("only 4-bit GPTQ is supported (exllamav2.py:105)")
@@ -326,6 +335,30 @@ def gptq_gemm_partial(x: torch.Tensor, w: GptqWeight, bias=None, act: int = 0) -
     return Partial(slabs, S, ld, M, w.N, bias)
 
 
+def gptq_rope_ok(M: int, w: GptqWeight, D: int) -> bool:
+    return bool(load_library().tgis_gptq_rope_ok(M, w.K, w.groups, int(w.perm is not None), D))
+
+
+def gptq_gemm_rope(x: torch.Tensor, w: GptqWeight, bias, cos, sin, positions, slots, k_pool, v_pool, H: int, Hkv: int,
+                   D: int, out=None) -> torch.Tensor:
+    """qkv projection + rotary embedding + cache write in one launch (decode, M <= 32; `w` is the rope image of the fused
+    qkv weight).  Returns a [M, (H + 2 Hkv) D] tensor whose first H D columns hold the rotated q (the k / v columns are not
+    written: they went straight into their cache pages)."""
+    assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == w.K
+    assert w.flags & 2 and w.N == (H + 2 * Hkv) * D
+    assert positions.dtype == torch.int32 and slots.dtype == torch.int32 and cos.dtype == torch.float16
+    assert cos.shape[1] * 2 == D, "the fused epilogue covers the full rotary span only"
+    M = x.shape[0]
+    if out is None:
+        out = torch.empty((M, w.N), dtype=torch.float16, device=x.device)
+    _check(
+        load_library().tgis_gptq_gemm_rope_f16(_ptr(x), x.stride(0), _ptr(w.image), _ptr(bias), _ptr(positions), _ptr(slots),
+                                               _ptr(cos), _ptr(sin), _ptr(out), out.stride(0), _ptr(k_pool), _ptr(v_pool),
+                                               M, w.K, w.N, w.groups, H, Hkv, D, _stream()),
+        "tgis_gptq_gemm_rope_f16")
+    return out
+
+
 # ---- lean decode GEMM: x travels with the row sums its producer computed ---------------------------------------------
 def xs_of(x: torch.Tensor) -> Optional[torch.Tensor]:
     """The row-sum side tensor `[M, K/16, 2]` fp32 a producer kernel attached to its f16 output (None if it did not)."""
@@ -345,6 +378,11 @@ def xsum(x: torch.Tensor) -> torch.Tensor:
     _check(load_library().tgis_xsum_f16(_ptr(x), x.stride(0), _ptr(xs), xs.stride(0) // 2, x.shape[0], x.shape[1],
                                         _stream()), "tgis_xsum_f16")
     return xs
+
+
+def gptq_lean_status(reset: bool = False) -> int:
+    """0, or the give-up code of a bounded wait inside the loader / consumer GEMM (synchronises)."""
+    return load_library().tgis_gptq_lean_status(int(reset))
 
 
 def gptq_lean_ok(M: int, w: GptqWeight, act: int = 0) -> bool:

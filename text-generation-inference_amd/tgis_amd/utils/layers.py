@@ -24,6 +24,9 @@ import os
 SKINNY_MAX_M = int(os.getenv("TGIS_SKINNY_MAX_M", "256"))
 # fuse the split-K reduce of decode-sized GPTQ GEMMs into the consumer kernel (rmsnorm / rope+KV write)
 DEFER_REDUCE = os.getenv("TGIS_DEFER_REDUCE", "true").lower() not in ("0", "false")
+# decode batches of up to 32 rows: rotary embedding + cache write in the epilogue of the int4 qkv GEMM (one launch
+# instead of GEMM + tgis_rope_kv_write, no split-K slabs).  Costs a second image of the qkv weights.
+FUSED_ROPE_GEMM = os.getenv("TGIS_FUSED_ROPE_GEMM", "true").lower() not in ("0", "false")
 
 _WORKSPACES = {}
 
@@ -94,11 +97,21 @@ class Ex4bitLinearV2:
         self.q_handle: Optional[native.GptqWeight] = None
         # set by LlamaMLP on the fused [gate | up] projection: SiLU(gate)*up runs in the GEMM epilogue
         self.gate_up = False
+        # set by FlashLlamaAttention on the fused qkv projection: (H, Hkv, D) of this shard -> post_init also builds the
+        # rope image (a second copy of the int4 matrix with rotation pairs inside each tile, +K*N/2 bytes) for
+        # native.gptq_gemm_rope, the decode launch that rotates q / k and writes the cache in its epilogue
+        self.rope_heads = None
+        self.rope_handle: Optional[native.GptqWeight] = None
         self._fused = {}  # act -> rows up to which the library's fused kernels are used
 
     def post_init(self):
         self.q_handle = native.GptqWeight(self.qweight, self.qzeros, self.scales, self.g_idx, self.bits,
                                           self.groupsize, gate_up=self.gate_up)
+        if self.rope_heads is not None and FUSED_ROPE_GEMM:
+            H, Hkv, D = self.rope_heads
+            if self.q_handle.perm is None and native.gptq_rope_ok(1, self.q_handle, D):
+                self.rope_handle = native.GptqWeight(self.qweight, self.qzeros, self.scales, None, self.bits,
+                                                     self.groupsize, rope=(D, H + Hkv))
         self.qweight = self.qzeros = self.scales = None  # the prepared image replaces them
 
     def _fused_rows(self, act: int) -> int:

@@ -71,8 +71,9 @@ def check():
                 p = nat.gptq_gemm_partial_lean(xd, xs, h)
                 sl = p.slabs[: p.S * 32 * p.ld].view(p.S, 32, p.ld).sum(0)[:m, :Nc].cpu()
                 line += f"  partial(S={p.S}) {(sl - ref_o).abs().max().item() / scale:.2e}"
-            print(line, flush=True)
-            assert e_new < 2e-3, "lean GEMM disagrees with the fp32 reference"
+            st = nat.gptq_lean_status(reset=True)
+            print(line + (f"  STATUS {st}" if st else ""), flush=True)
+            assert st == 0 and e_new < 2e-3, "lean GEMM disagrees with the fp32 reference"
 
 
 def bench():
@@ -96,6 +97,8 @@ def bench():
         else:
             t_old = timeit(lambda i: nat.gptq_gemm_partial(x, hs[i]), sets)
             t_new = timeit(lambda i: nat.gptq_gemm_partial_lean(x, xs, hs[i]), sets)
+        st = nat.gptq_lean_status(reset=True)
+        assert st == 0, f"in-kernel wait gave up: code {st}"
         print(f"{name:8s} M={M} {K}x{N}: old {t_old*1e6:6.2f} us ({byts/t_old/1e12:.2f} TB/s)   lean {t_new*1e6:6.2f} us "
               f"({byts/t_new/1e12:.2f} TB/s)", flush=True)
 
