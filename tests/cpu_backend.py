@@ -18,8 +18,9 @@ class _Workspace:
 
 
 class _GptqWeight:
-    def __init__(self, qweight, qzeros, scales, g_idx, bits, groupsize, gate_up=False):
-        self.flags = 1 if gate_up else 0
+    def __init__(self, qweight, qzeros, scales, g_idx, bits, groupsize, gate_up=False, rope=None):
+        # (the rope image only re-orders columns inside the device image: the stand-in keeps the natural order)
+        self.flags = 1 if gate_up else (2 if rope is not None else 0)
         self.K, self.N = qweight.shape[0] * 8, qweight.shape[1]
         self.groups = qzeros.shape[0]
         self.perm = None
@@ -164,6 +165,9 @@ def install(monkeypatch):
         argmax_logprob=_argmax_logprob, attn_num_splits=lambda *a: 1, attn_workspace_bytes=lambda *a: 0,
         act_mul=lambda gu, I, out=None: ops_ref.silu_mul(gu, I).to(gu.dtype),
         gptq_gemm_partial=lambda x, w, bias=None, act=0: _gptq_gemm(x, w, None, bias=bias, act=act),
+        gptq_rope_ok=lambda M, w, D: 1 <= M <= 32 and w.perm is None,
+        gptq_gemm_rope=lambda x, w, bias, cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, out=None: _rope_kv_write(
+            _gptq_gemm(x, w, None, bias=bias), cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, D),
         dense_gemm_partial=lambda x, w, bias=None, act=0: _dense_gemm(x, w, None, bias=bias, act=act),
     ).items():
         monkeypatch.setattr(native, name, fn)

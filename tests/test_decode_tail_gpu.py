@@ -26,6 +26,11 @@ def _build(cfg_kw, layers, seed, use_tail, monkeypatch, B, L, steps, quantize="g
     from tgis_amd.utils.kv_cache import PagedKVCache
 
     M.DECODE_TAIL = use_tail
+    # the comparison is between the tail's phases and the SAME units as separate launches: the fused qkv + rope launch of
+    # round 3 keeps the whole k range in one block (another summation order), so the reference path here runs without it
+    from tgis_amd.utils import layers as _layers
+
+    monkeypatch.setattr(_layers, "FUSED_ROPE_GEMM", False)
     cfg = M.LlamaConfig(num_hidden_layers=layers, max_position_embeddings=4096, **cfg_kw)
     tensors = llama_tensors(cfg, quantize, seed=seed, device="cpu", dtype=dtype)
     tok = FixtureTokenizer(cfg.vocab_size)

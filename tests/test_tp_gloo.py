@@ -155,3 +155,38 @@ def test_row_parallel_gptq_regroups_misaligned_shards(K, gs, world):
             assert lgs == gs, "aligned shards keep the checkpoint's groups"
         local = ops_ref.gptq_dequant(lqw.numpy(), lqz.numpy(), lsc.numpy(), None, lgs)
         assert torch.equal(local, full[rank * rows:(rank + 1) * rows])
+
+
+def _pages_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    import types
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "text-generation-inference_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from tgis_amd.models.flash_causal_lm import FlashCausalLM
+    from tgis_amd.utils.dist import initialize_torch_distributed
+
+    pg = initialize_torch_distributed(world, rank)
+    engine = types.SimpleNamespace(process_group=pg, world_size=world)
+    me = types.SimpleNamespace(device=torch.device("cpu"))
+    ret[rank] = FlashCausalLM._agree_on_min(me, 1000 - 137 * rank, engine)
+
+
+def test_tp_ranks_agree_on_the_smallest_page_pool():
+    """Every tensor-parallel rank must build the same page pool (the rank with the least free memory decides): with
+    lazily grown pages a rank that runs out first would leave a decode step its peers have already entered."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_pages_worker, args=(r, world, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        assert dict(ret) == {0: 863, 1: 863}

@@ -18,6 +18,8 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
+#include <map>
+#include <mutex>
 #include "common.h"
 #include "attention_args.h"
 #include "kv_layout.h"
@@ -595,32 +597,51 @@ extern "C" int64_t tgis_attn_workspace_bytes(int64_t total_q_tokens, int H, int 
 
 namespace {
 constexpr int64_t ATTN_COUNTERS = 1 << 20;
-unsigned* g_attn_counters[16] = {};
+constexpr int ATTN_COUNTER_SETS = 4;
 
 // Arrival counters of the fused combine, one per group; zero between launches (the last arriver resets its own).
-// Owned by the library, one array per device: launches that may overlap on one device (several streams) must not
-// both use key splits.  Never allocated while the stream is capturing (the first, un-captured call does it).
+// Owned by the library: a pool of ATTN_COUNTER_SETS arrays per device, handed out per STREAM — two split-key launches that
+// overlap on one device are necessarily on different streams, so they never share an array (launches of one stream are
+// ordered).  The pool is allocated by the first call that is not inside a stream capture (the eager warm-up step); handing
+// an array of the pool to a new stream needs no allocation, so a capture stream gets one too.  A fifth concurrent stream,
+// or a capture before any eager call, falls back to the separate combine launch.
+struct CounterPool {
+    unsigned* sets[ATTN_COUNTER_SETS] = {};
+    hipStream_t owner[ATTN_COUNTER_SETS] = {};
+    int used = 0;
+    bool ready = false;
+};
+std::mutex g_attn_counters_mu;
+std::map<int, CounterPool> g_attn_counters;
+
 unsigned* attn_counters(hipStream_t st) {
+    static const bool off = getenv("TGIS_ATTN_FUSED_COMBINE") && atoi(getenv("TGIS_ATTN_FUSED_COMBINE")) == 0;
+    if (off) return nullptr;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!g_attn_counters[dev]) {
-        static const bool off = getenv("TGIS_ATTN_FUSED_COMBINE") && atoi(getenv("TGIS_ATTN_FUSED_COMBINE")) == 0;
-        if (off) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_attn_counters_mu);
+    CounterPool& pool = g_attn_counters[dev];
+    if (!pool.ready) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
             (void)hipGetLastError();
             return nullptr;
         }
         unsigned* p = nullptr;
-        if (hipMalloc((void**)&p, ATTN_COUNTERS * sizeof(unsigned)) != hipSuccess ||
-            hipMemset(p, 0, ATTN_COUNTERS * sizeof(unsigned)) != hipSuccess) {
+        const size_t bytes = (size_t)ATTN_COUNTER_SETS * ATTN_COUNTERS * sizeof(unsigned);
+        if (hipMalloc((void**)&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;
         }
         (void)hipDeviceSynchronize();
-        g_attn_counters[dev] = p;
+        for (int i = 0; i < ATTN_COUNTER_SETS; ++i) pool.sets[i] = p + (size_t)i * ATTN_COUNTERS;
+        pool.ready = true;
     }
-    return g_attn_counters[dev];
+    for (int i = 0; i < pool.used; ++i)
+        if (pool.owner[i] == st) return pool.sets[i];
+    if (pool.used == ATTN_COUNTER_SETS) return nullptr;
+    pool.owner[pool.used] = st;
+    return pool.sets[pool.used++];
 }
 }  // namespace
 

@@ -19,6 +19,13 @@
 
 namespace gptq {
 
+// Measurement switches of tools/lean_gemm.py builds (-DLEAN_DBG=bits, wrong results): 1 no x loads, 2 no row-sum loads,
+// 4 no scale loads, 8 consumers do not wait for / read fresh ring data, 16 the loader issues nothing.
+#ifndef LEAN_DBG
+#define LEAN_DBG 0
+#endif
+constexpr int LD_DBG = LEAN_DBG;
+
 constexpr int KCL = 128;      // k per x chunk = one group = two wave-steps
 constexpr int RSL = KCL + 8;  // LDS row stride in halves (+16 B: conflict-free ds_read_b128)
 constexpr int LD_XBYTES = 2 * 32 * RSL * (int)sizeof(f16);  // x chunk double buffer of one k-part
@@ -86,7 +93,7 @@ __device__ __forceinline__ void gptq_ld_unit(const LeanArgs& la, const int ntg, 
             kclamp[k] = min(ks_last, max(k0 >> 6, ((k1 + 63) >> 6) - 1));
         }
         const uint32_t woff = lane * 16;
-        if (la.dbg & 16) {
+        if (LD_DBG & 16) {
             if (lane == 0) *landed = nsteps * NC;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -166,7 +173,7 @@ __device__ __forceinline__ void gptq_ld_unit(const LeanArgs& la, const int ntg, 
     auto sz_at = [&](int grp) -> uint32_t {
         const char* p = sztile + (int64_t)min(g0 + grp, a.G - 1) * 128;
         PIN_SGPR(p);
-        if (la.dbg & 4) return 0x64003c00u;
+        if (LD_DBG & 4) return 0x64003c00u;
         const uint32_t v = *(const GLOBAL_AS uint32_t*)(p + szoff);
         return g0 + grp < g_end ? v : 0u;
     };
@@ -187,14 +194,14 @@ __device__ __forceinline__ void gptq_ld_unit(const LeanArgs& la, const int ntg, 
         const int kc = min(k0 + chunk * KCL + pcol, a.K - 8);
         const char* xb = reinterpret_cast<const char*>(a.x);
         PIN_SGPR(xb);
-        if (!(la.dbg & 1)) {
+        if (!(LD_DBG & 1)) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) xg[j] = *(const GLOBAL_AS f16x8*)(xb + rowoff[j] + (uint32_t)kc * 2);
         }
         const char* sb = reinterpret_cast<const char*>(la.xs);
         PIN_SGPR(sb);
         const int kb = min(((k0 + chunk * KCL) >> 4) + (ltid & 3) * 2, kb_last);
-        if (!(la.dbg & 2)) xq = *(const GLOBAL_AS f32x4*)(sb + ((size_t)xsrow + (uint32_t)kb) * 8);
+        if (!(LD_DBG & 2)) xq = *(const GLOBAL_AS f32x4*)(sb + ((size_t)xsrow + (uint32_t)kb) * 8);
     };
     auto stage_store = [&](int buf) {
 #pragma unroll
@@ -247,7 +254,7 @@ __device__ __forceinline__ void gptq_ld_unit(const LeanArgs& la, const int ntg, 
         if (more) stage_load(j + 1);
         const uint32_t szfar = sz_at(j + 2);
         // both steps of this chunk have landed once the second one has (DMAs land in issue order)
-        const int need = (la.dbg & 8) ? 0 : (2 * j + 1) * NC + c + 1;
+        const int need = (LD_DBG & 8) ? 0 : (2 * j + 1) * NC + c + 1;
         for (unsigned spins = 0; __builtin_amdgcn_readfirstlane(*landed) < need; ++spins) {
             __builtin_amdgcn_s_sleep(1);
             if (spins > LD_SPIN_LIMIT) {

@@ -63,7 +63,7 @@ int launch_one(dim3 grid, hipStream_t st, const LeanArgs& a) {
 
 // 0: register-ring kernel, 1: loader / consumer kernel (LDS-DMA ring)
 int use_ld() {
-    static const int v = getenv("TGIS_LEAN_LD") ? atoi(getenv("TGIS_LEAN_LD")) : 1;
+    static const int v = getenv("TGIS_LEAN_LD") ? atoi(getenv("TGIS_LEAN_LD")) : 0;
     return v;
 }
 int ld_depth() {
@@ -139,8 +139,6 @@ int launch_lean(const void* x, int64_t ldx, const float* xs, int64_t ldxs, const
     la.xs = xs;
     la.ldxs = ldxs;
     la.xs_out = xs_out;
-    static const int dbg = getenv("TGIS_LEAN_DBG") ? atoi(getenv("TGIS_LEAN_DBG")) : 0;
-    la.dbg = dbg;
     int rc;
     if (use_ld()) {
         // one wave of the workgroup is the loader: at most 15 consumers (4 x 4 plans run as 3 x 4)

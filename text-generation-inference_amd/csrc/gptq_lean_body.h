@@ -29,8 +29,6 @@ struct LeanArgs {
     const float* xs;   // [M][ldxs][2] fp32: {XA, XB} of x per row and 16 k
     int64_t ldxs;      // 16-k blocks per row of xs (>= K / 16)
     float* xs_out;     // act == 2: the same sums of the activated output [M][N/32][2] (nullptr: not wanted)
-    int dbg;           // measurement switches (TGIS_LEAN_DBG, wrong results): 1 no x loads, 2 no row-sum loads, 4 no scale
-                       // loads, 8 consumers do not wait for / read the ring, 16 the loader issues nothing
 };
 
 constexpr int LEAN_XBYTES = 2 * 32 * RS * (int)sizeof(f16);  // x chunk double buffer of one k-part
@@ -137,6 +135,7 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
     constexpr int NQ = (256 + GT - 1) / GT;         // quarter-tasks of the row-sum staging per thread per chunk
     constexpr int RG = RING / 2;                    // groups in the ring
     const int tid = threadIdx.x, lane = tid & 63;
+    TRACE(0);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = w % TN, wk = w / TN, ltid = wn * 64 + lane;
     f16* xs = reinterpret_cast<f16*>(smem + wk * LEAN_XBYTES);                         // [2][32][RS]
@@ -175,7 +174,7 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
     // ---- x staging (as gptq_gemm_unit) + row-sum staging ------------------------------------------------------------
     const f16* xbase = a.x;
     const int srow = ltid >> 5, scol = (ltid & 31) * 8;
-    f16x8 xg[NJ];
+    f16x8 xg[NJ] = {};
     uint32_t rowoff[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) rowoff[j] = (uint32_t)(min(srow + RSTEP * j, mrows - 1) * (int)a.ldx * 2);
@@ -192,8 +191,10 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
         const int kc = min(k0 + chunk * KC + scol, a.K - 8);
         const char* xb = reinterpret_cast<const char*>(xbase);
         PIN_SGPR(xb);
+#if !defined(LEAN_ABL) || !(LEAN_ABL & 4)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) xg[j] = *(const GLOBAL_AS f16x8*)(xb + rowoff[j] + (uint32_t)kc * 2);
+#endif
         const char* sb = reinterpret_cast<const char*>(la.xs);
         PIN_SGPR(sb);
         const int kb0 = (k0 + chunk * KC) >> 4;
@@ -248,6 +249,7 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
     for (int s = 0; s < RG; ++s) szg[s] = sz_at(s);
 #pragma unroll
     for (int s = 0; s < RING; ++s) wq[s] = w_at(s);
+    TRACE(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     auto group_sync = [&](int target) {
@@ -258,6 +260,7 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
     };
     stage_store(0);
     group_sync(TN);
+    TRACE(2);
 
     // One chunk = 4 k64-steps = 2 groups.  SB: first ring slot of the chunk; STAGE: a next chunk exists; REFILL: the chunk
     // RING / 4 ahead exists (its weights and scales replace this chunk's in place).
@@ -292,15 +295,28 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
                 const u32x4 cur = wq[SB + s4];
                 const f16* xk = xbuf + s4 * 64;
                 f16x8 b[4];
+#if defined(LEAN_ABL) && (LEAN_ABL & 32)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = __builtin_bit_cast(f16x8, u32x4{cur[i], cur[i], cur[i], cur[i]});
+#else
 #pragma unroll
                 for (int i = 0; i < 4; ++i) b[i] = unpack8(cur[i], EXA, EXB, M0r, M1r);
+#endif
+#if !defined(LEAN_ABL) || !(LEAN_ABL & 16)
                 if (REFILL) {
                     __builtin_amdgcn_sched_barrier(0);
                     wq[SB + s4] = w_at(step + RING);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#else
+                wq[SB + s4][0] += step;
+#endif
+#if defined(LEAN_ABL) && (LEAN_ABL & 32)
+                g[0] += (float)(b[0][0] + b[1][1] + b[2][2] + b[3][3]);
+#else
 #pragma unroll
                 for (int i = 0; i < 4; ++i) g = mfma32(ld16<f16x8>(xk + i * 8), b[i], g);
+#endif
             }
 #if defined(LEAN_ABL) && (LEAN_ABL & 1)
             acc = g;
@@ -316,8 +332,12 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
             for (int gi = 0; gi < 2; ++gi) szg[SB / 2 + gi] = szn[gi];
         }
         if (!STAGE) return;
+#if !defined(LEAN_ABL) || !(LEAN_ABL & 8)
         stage_store((chunk + 1) & 1);
+        TRACE(3 + 2 * min(chunk, 3));
         group_sync(TN * (chunk + 2));
+        TRACE(4 + 2 * min(chunk, 3));
+#endif
     };
     using I0 = std::integral_constant<int, 0>;
     using I4 = std::integral_constant<int, 4>;
@@ -344,6 +364,7 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
             chunk_body(chunk, I0{}, N{}, N{});
         }
     }
+    TRACE(9);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every k-part is done with its x buffers: the reduction below reuses them
 
@@ -358,6 +379,7 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        TRACE(11);
         if (wk > 0) return;
 #pragma unroll
         for (int k2 = 1; k2 < WK; ++k2) {
@@ -373,7 +395,9 @@ __device__ __forceinline__ void gptq_lean_unit(const LeanArgs& la, const int ntg
         }
     }
 
+    TRACE(12);
     lean_epilogue<ACT>(la, acc, nt_raw, nt, split, mrows, lane);
+    TRACE(13);
 }
 
 // Whether the lean kernel covers this GEMM (otherwise the caller keeps gptq_gemm_kernel).

@@ -72,4 +72,9 @@ def get_model(model_name: str, revision: Optional[str], deployment_framework: st
         raise NotImplementedError(f"Unsupported model type {model_type}")
     from tgis_amd.models.causal_lm import CausalLM
 
+    if deployment_framework == "tgis_native":
+        # the native engine only builds the flash model classes; the padded batch type runs the library model
+        print_rank_n("WARNING: Using deployment engine hf_transformers rather than tgis_native because FLASH_ATTENTION "
+                     "is disabled (the tgis_native engine serves the flash path only)")
+        deployment_framework = "hf_transformers"
     return CausalLM(model_name, revision, deployment_framework, dtype, quantize, model_config, max_sequence_length)

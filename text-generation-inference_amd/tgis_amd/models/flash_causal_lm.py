@@ -415,6 +415,11 @@ class FlashCausalLM(Model):
             self.model.post_init()
         if kv_cache_pages is None:
             kv_cache_pages = self._default_kv_pages()
+        # Tensor parallel: every rank must hold the SAME number of pages.  Each rank sizes its pool from its own free
+        # memory, and `grow_pages` raises OutOfPages before a decode step: a rank with fewer pages would leave the step
+        # while the others enter its all-reduces (a hang instead of RESOURCE_EXHAUSTED), and the memory model a rank
+        # reports to the router would differ from its peers'.  The smallest pool decides.
+        kv_cache_pages = self._agree_on_min(kv_cache_pages, engine)
         self.kv_cache = PagedKVCache(self.num_layers, self.num_kv_heads, self.head_size, kv_cache_pages, dtype,
                                      self.device)
         # tp > 1, TGIS_TP_GRAPHS = auto (default) | full | segments | false:
@@ -498,6 +503,17 @@ class FlashCausalLM(Model):
         flag = torch.tensor([1 if ok else 0], device=self.device, dtype=torch.int32)
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=pg)
         return bool(flag.item())
+
+    def _agree_on_min(self, value: int, engine) -> int:
+        """min of `value` over the tensor-parallel group (all-reduce MIN); the value itself on one rank."""
+        pg = getattr(engine, "process_group", None)
+        world = engine.world_size if hasattr(engine, "world_size") else 1
+        if world == 1 or not isinstance(pg, torch.distributed.ProcessGroup):
+            return int(value)
+        dev = self.device if torch.distributed.get_backend(pg) == "nccl" else torch.device("cpu")
+        t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN, group=pg)
+        return int(t.item())
 
     def _default_kv_pages(self) -> int:
         free, _total = torch.cuda.mem_get_info(self.device)

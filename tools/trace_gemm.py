@@ -21,8 +21,9 @@ from tgis_amd import native as nat  # noqa: E402
 
 K, N = int(sys.argv[1]), int(sys.argv[2])
 act = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-if len(sys.argv) > 4:
+if len(sys.argv) > 4 and sys.argv[4] != "-":
     os.environ["TGIS_GPTQ_PLAN"] = sys.argv[4]
+LEAN = len(sys.argv) > 5 and sys.argv[5] == "lean"  # the lean kernel (TGIS_LEAN_RING / TGIS_LEAN_LD select its form)
 dev = torch.device("cuda:0")
 gs, M = 128, 32
 G = K // gs
@@ -37,17 +38,21 @@ ws = nat.Workspace(sets[0].workspace_bytes(M), dev)
 NB = 4096
 trace = torch.zeros(NB * 16 * 32, dtype=torch.int64, device=dev)
 L = nat.load_library()
-L.tgis_debug_set_trace.argtypes = [ctypes.c_void_p]
+set_trace = L.tgis_debug_set_trace_lean if LEAN else L.tgis_debug_set_trace
+set_trace.argtypes = [ctypes.c_void_p]
+xs = nat.xsum(x)
 
 
 def run(i):
+    if LEAN:
+        return nat.gptq_gemm_lean(x, xs, sets[i], ws, act=act)
     return nat.gptq_gemm(x, sets[i], ws, act=act)
 
 
 for i in range(3):
     run(i)
 torch.cuda.synchronize()
-assert L.tgis_debug_set_trace(ctypes.c_void_p(trace.data_ptr())) == 0
+assert set_trace(ctypes.c_void_p(trace.data_ptr())) == 0
 trace.zero_()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
@@ -60,9 +65,9 @@ used = t[:, :, 0] != 0
 t0 = t[:, :, 0][used].min().item()
 names = {0: "entry", 1: "weights issued", 2: "x0 staged+barrier", 3: "chunk0 done", 4: "chunk0 barrier", 5: "chunk1 done",
          6: "chunk1 barrier", 7: "chunk2 done", 8: "chunk2 barrier", 9: "last chunk done", 10: "last barrier",
-         11: "reduce barrier", 12: "epilogue start"}
+         11: "reduce barrier", 12: "epilogue start", 13: "epilogue done"}
 print(f"blocks used: {int(used.any(dim=1).sum())}, waves: {int(used.sum())}   (ticks of s_memtime, relative to first entry)")
-for i in range(13):
+for i in range(14):
     v = t[:, :, i]
     m = v != 0
     if not m.any():
@@ -76,7 +81,7 @@ for i in range(4):
     names[17 + 4 * i] = f"c1 step{i} dequant done"
     names[18 + 4 * i] = f"c1 step{i} mfma issued"
 names[9] = "last chunk done"
-pairs = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (6, 9), (4, 9), (2, 9), (9, 11), (11, 12), (0, 12)]
+pairs = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (6, 9), (4, 9), (2, 9), (9, 11), (11, 12), (12, 13), (0, 12)]
 for a_, b_ in pairs:
     va, vb = t[:, :, a_], t[:, :, b_]
     m = (va != 0) & (vb != 0)
@@ -87,6 +92,8 @@ for a_, b_ in pairs:
 # chip-wide picture from s_memrealtime (100 MHz): when do waves enter, when do reducer waves reach the epilogue
 rt0, rt1 = t[:, :, 14], t[:, :, 15]
 m0, m1 = rt0 != 0, rt1 != 0
+if not (m0.any() and m1.any()):
+    sys.exit(0)
 base = rt0[m0].min().item()
 e = (rt0[m0] - base).float() * 10.0
 x = (rt1[m1] - base).float() * 10.0
