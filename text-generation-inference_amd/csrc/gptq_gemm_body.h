@@ -328,6 +328,14 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
     // Issue order matters: a wave's loads return in order, so the (L2-resident) first x chunk goes out before the
     // HBM weight stream it would otherwise queue behind; then the small scale loads, then the ring of weights.
     stage_load(0);
+#ifndef TGIS_NO_XFIRST_BARRIER
+    // Stand-alone kernel: the block-wide barrier that publishes the zeroed counters sits HERE, between the x requests and
+    // the weight requests of every wave.  A CU serves its waves' requests in arrival order: without it a later wave's
+    // first x chunk queues behind the HBM weight requests of the waves that started before it, and the first chunk was
+    // staged only when the whole first ring had arrived (3.1 us after entry for gate_up); with it every x request of the
+    // block is in front of every weight request.
+    if (!TAIL) unit_barrier();
+#endif
     if (MODE == UNIT_FULL) {
 #pragma unroll
         for (int s = 0; s < RING; ++s)
@@ -337,7 +345,11 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
     }
     // the only block-wide barrier before the reduction publishes the zeroed counters; it does not wait for the loads
     // above, and from here on each k-part group paces itself
+#ifndef TGIS_NO_XFIRST_BARRIER
+    if (TAIL) unit_barrier();
+#else
     unit_barrier();
+#endif
     auto group_sync = [&](int target) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add((lds_int*)sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
