@@ -122,14 +122,23 @@ int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void* prepared,
  * stores q to q_out[M, ldq] and k / v into the cache pages of slots[m] (page layouts of tgis_rope_kv_write).
  * `prepared` is a SECOND image of the qkv weight made with flags = TGIS_GPTQ_ROPE_IMAGE(D, H + Hkv): inside each rotated
  * head a 32-column tile holds 16 dims and their 16 rotation partners, so every wave owns complete rotation pairs.
- * Full rotary span only (rot_dim == D).  tgis_gptq_rope_ok: 1 <= M <= 32, groups of 64 * 2^n rows, no act-order,
- * D % 32 == 0. */
+ * Full rotary span only (rot_dim == D).  tgis_gptq_rope_ok: whether the launch exists for the shape (1 <= M <= 64, groups
+ * of 64 * 2^n rows, no act-order, D % 32 == 0) AND is expected to beat the two launches it replaces (its unsplit plan
+ * still covers the chip, or the matrix is launch-bound anyway); the entry point itself only checks the former. */
 #define TGIS_GPTQ_ROPE_IMAGE(D, rotated_heads) (2 | ((int)(D) << 8) | ((int)(rotated_heads) << 20))
-int tgis_gptq_rope_ok(int64_t M, int64_t K, int64_t groups, int act_order, int64_t D);
+int tgis_gptq_rope_ok(int64_t M, int64_t K, int64_t N, int64_t groups, int act_order, int64_t D);
 int tgis_gptq_gemm_rope_f16(const void* x, int64_t ldx, const void* prepared, const void* bias, const int32_t* positions,
                             const int32_t* slots, const void* cos, const void* sin, void* q_out, int64_t ldq,
                             void* k_pool, void* v_pool, int64_t M, int64_t K, int64_t N, int64_t groups, int64_t H,
                             int64_t Hkv, int64_t D, void* stream);
+
+/* The same launch for dense (f16 / bf16) qkv weights: `prepared` from tgis_dense_prepare with
+ * flags = TGIS_GPTQ_ROPE_IMAGE(D, H + Hkv); cos / sin in the model dtype; 1 <= M <= 64. */
+int tgis_dense_rope_ok(int64_t M, int64_t K, int64_t N, int64_t D);
+int tgis_dense_gemm_rope(const void* x, int64_t ldx, const void* prepared, const void* bias, const int32_t* positions,
+                         const int32_t* slots, const void* cos, const void* sin, void* q_out, int64_t ldq, void* k_pool,
+                         void* v_pool, int64_t M, int64_t K, int64_t N, int64_t H, int64_t Hkv, int64_t D, int dtype,
+                         void* stream);
 
 /* ---- "lean" decode GEMM (round 3) -------------------------------------------------------------------------------
  * Same contract as tgis_gptq_gemm_f16 / tgis_gptq_gemm_f16_partial (the gemm_half_q_half call of

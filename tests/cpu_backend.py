@@ -36,7 +36,7 @@ class _GptqWeight:
 
 
 class _DenseWeight:
-    def __init__(self, weight, gate_up=False):
+    def __init__(self, weight, gate_up=False, rope=None):
         self.N, self.K = weight.shape
         self.dtype = weight.dtype
         self.flags = 1 if gate_up else 0
@@ -165,7 +165,10 @@ def install(monkeypatch):
         argmax_logprob=_argmax_logprob, attn_num_splits=lambda *a: 1, attn_workspace_bytes=lambda *a: 0,
         act_mul=lambda gu, I, out=None: ops_ref.silu_mul(gu, I).to(gu.dtype),
         gptq_gemm_partial=lambda x, w, bias=None, act=0: _gptq_gemm(x, w, None, bias=bias, act=act),
-        gptq_rope_ok=lambda M, w, D: 1 <= M <= 32 and w.perm is None,
+        gptq_rope_ok=lambda M, w, D: 1 <= M <= 64 and w.perm is None,
+        rope_gemm_ok=lambda M, w, D: 1 <= M <= 64 and getattr(w, "perm", None) is None,
+        dense_gemm_rope=lambda x, w, bias, cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, out=None: _rope_kv_write(
+            _dense_gemm(x, w, None, bias=bias), cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, D),
         gptq_gemm_rope=lambda x, w, bias, cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, out=None: _rope_kv_write(
             _gptq_gemm(x, w, None, bias=bias), cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, D),
         dense_gemm_partial=lambda x, w, bias=None, act=0: _dense_gemm(x, w, None, bias=bias, act=act),

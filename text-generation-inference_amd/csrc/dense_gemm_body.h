@@ -8,6 +8,7 @@
 //   whose LDS layout constants (x region, control line) the dense unit shares.
 #pragma once
 #include "gptq_gemm_body.h"
+#include "kv_layout.h"
 
 namespace dense {
 
@@ -33,6 +34,15 @@ struct DenseArgs {
     float* slabs;  // [Mslabs][S][32][NT*32] f32 partial sums (S > 1 or partial mode)
     int partial;   // 1: always leave fp32 slabs (deferred reduce), never write `out`
     unsigned* err; // decode tail: word that receives a code when a bounded spin gives up (nullptr otherwise)
+    // ACT == 3 (rope image, tgis_dense_prepare flags bit 1): the epilogue rotates q / k heads and writes k / v into their
+    // cache pages; `out` is the q tensor (see tgis_dense_gemm_rope)
+    const int32_t* positions;  // [M]
+    const int32_t* slots;      // [M] page * 32 + token
+    const void* cosb;          // [max_pos][rD / 2], model dtype
+    const void* sinb;
+    void* kpool;               // [pages][rHkv][32 * rD] in the K page layout of kv_layout.h
+    void* vpool;
+    int rH, rHkv, rD;
 };
 
 constexpr int DKC = 256;      // k per LDS chunk (4 k64-steps)
@@ -63,6 +73,7 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
                                                 unsigned char* smem, const int ub_base, DenseRing<T>& ring) {
     static_assert(MR == 1 || WK == 2, "64-row passes need the LDS of two k-parts");
     static_assert(!TAIL || MR == 1, "the decode tail runs 32-row units");
+    static_assert(ACT != 3 || !TAIL, "the rope epilogue belongs to the stand-alone kernel");
     using V8 = typename VecT<T>::x8;
     constexpr int NWAVES = TN * WK;
     constexpr int XR = 32 * MR;
@@ -98,6 +109,20 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
 #pragma unroll
         for (int s = 0; s < DRING; ++s) w_load(s, wq[s]);
         return;
+    }
+
+    // ACT 3: cache slot and rotary position of the rows this wave will finish (distributed finish below)
+    int32_t rpos[ACT == 3 ? MR : 1][ACT == 3 ? 16 / WK : 1], rslot[ACT == 3 ? MR : 1][ACT == 3 ? 16 / WK : 1];
+    if (ACT == 3) {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int j = 0; j < 16 / WK; ++j) {
+                const int r = wk * (16 / WK) + j;
+                const int m = min(mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), mrows - 1);
+                rpos[mr][j] = a.positions[m0 + m];
+                rslot[mr][j] = a.slots[m0 + m];
+            }
     }
 
     // ---- x staging: rows past M read a clamped row (their outputs are never stored); columns past the k-range are
@@ -183,11 +208,15 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
     };
     if (wn == 0 && lane == 0) *sync_cnt = 0;
     stage_load(0);  // x first: a wave's loads return in order and this one is L2-resident
+    // stand-alone kernel: the barrier that publishes the zeroed counters sits between the x requests and the weight
+    // requests of EVERY wave, so that no wave's first x chunk queues behind another wave's HBM requests in the CU's
+    // memory pipeline (as in gptq_gemm_unit)
+    if (!TAIL) unit_barrier();
     if (MODE == UNIT_FULL) {
 #pragma unroll
         for (int s = 0; s < DRING; ++s) w_load(s, wq[s]);
     }
-    unit_barrier();  // publishes the zeroed counters; does not wait for the loads above
+    if (TAIL) unit_barrier();  // publishes the zeroed counters; does not wait for the loads above
     auto group_sync = [&](int target) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add((lds_int*)sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -238,11 +267,148 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
     };
     for (int chunk = 0; chunk + 1 < nchunks; ++chunk) chunk_body(chunk, std::false_type{});
     chunk_body(nchunks - 1, std::true_type{});
+    // stand-alone kernel, ACT 3: the cos / sin entries of the rows this wave will finish, asked for before the exchange
+    constexpr int NR = 16 / WK;
+    T rcos[ACT == 3 ? MR : 1][ACT == 3 ? NR : 1], rsin[ACT == 3 ? MR : 1][ACT == 3 ? NR : 1];
+    if (ACT == 3) {
+        const int per = a.rD >> 5;
+        const int tt = nt - (nt / per) * per;
+        const int dr = 16 * tt + (lane & 15);
+        const bool roth = nt / per < a.rH + a.rHkv;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                rcos[mr][j] = roth ? reinterpret_cast<const T*>(a.cosb)[(int64_t)rpos[mr][j] * (a.rD >> 1) + dr] : (T)1.f;
+                rsin[mr][j] = roth ? reinterpret_cast<const T*>(a.sinb)[(int64_t)rpos[mr][j] * (a.rD >> 1) + dr] : (T)0.f;
+            }
+    }
     unit_barrier();  // every k-part is done with its x buffers: the reduction below reuses them
 
     f32x16 acc[MR];
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) acc[mr] = accs[mr][0] + accs[mr][1];
+    // ---- stand-alone kernel: distributed finish (as gptq_gemm_unit) -----------------------------------------------------
+    // Every wave leaves its partial sums in LDS; wave (wn, wk) sums the WK k-parts of accumulator registers
+    // [wk NR, (wk + 1) NR) of tile wn in the fixed order 0..WK-1 (bit-identical to the reducer-wave form) and runs the
+    // epilogue for those rows only.
+    if (!TAIL && WK > 1) {
+        float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][MR][64 lanes][16]
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            float* dst = red + ((((wk * TN + wn) * MR + mr) * 64 + lane) << 4);
+#pragma unroll
+            for (int r = 0; r < 16; r += 4)
+                *reinterpret_cast<f32x4*>(dst + r) = f32x4{acc[mr][r], acc[mr][r + 1], acc[mr][r + 2], acc[mr][r + 3]};
+        }
+        unit_barrier();
+        if (nt_raw >= a.NT) return;
+        float fin[MR][NR];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int k2 = 0; k2 < WK; ++k2) {
+                const float* src = red + ((((k2 * TN + wn) * MR + mr) * 64 + lane) << 4) + wk * NR;
+#pragma unroll
+                for (int j = 0; j < NR; j += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(src + j);
+                    if (k2 == 0) {
+                        fin[mr][j] = t[0], fin[mr][j + 1] = t[1], fin[mr][j + 2] = t[2], fin[mr][j + 3] = t[3];
+                    } else {
+                        fin[mr][j] += t[0], fin[mr][j + 1] += t[1], fin[mr][j + 2] += t[2], fin[mr][j + 3] += t[3];
+                    }
+                }
+            }
+        const int c = lane & 31;
+        auto row_of = [&](int j) {
+            const int r = wk * NR + j;
+            return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        };
+        if (ACT == 3) {
+            // rope image: a tile of a q / k head holds dims [16 t, 16 t + 16) in lanes c < 16 and their rotation partners
+            // rD/2 + [16 t, ..) in lanes c + 16; v heads keep 32 consecutive dims.  Sum (+ bias) rounded to T, rotated in
+            // fp32 (the arithmetic of rope_kv_kernel), q to `out`, k / v into their cache pages.  Host guarantees S == 1.
+            const int per = a.rD >> 5;
+            const int head = nt / per, tt = nt - head * per;
+            const bool roth = head < a.rH + a.rHkv;
+            const int d = roth ? ((c < 16) ? 16 * tt + c : (a.rD >> 1) + 16 * tt + (c - 16)) : 32 * tt + c;
+            const int col = head * a.rD + d;
+            const float bv = a.bias ? to_f32(reinterpret_cast<const T*>(a.bias)[col]) : 0.f;
+            T* kpool = reinterpret_cast<T*>(a.kpool);
+            T* vpool = reinterpret_cast<T*>(a.vpool);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int m = mr * 32 + row_of(j);
+                    const float mine = to_f32(from_f32<T>(fin[mr][j] + bv));
+                    float o = mine;
+                    if (roth) {
+                        const float other = __shfl_xor(mine, 16, 64);
+                        const float cf = to_f32(rcos[mr][j]), sf = to_f32(rsin[mr][j]);
+                        o = (c < 16) ? mine * cf - other * sf : other * sf + mine * cf;
+                    }
+                    const T oh = from_f32<T>(o);
+                    if (m < mrows) {
+                        if (head < a.rH) {
+                            reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + col] = oh;
+                        } else {
+                            const int page = rslot[mr][j] >> 5, tok = rslot[mr][j] & 31;
+                            if (roth)
+                                kpool[((int64_t)page * a.rHkv + (head - a.rH)) * 32 * a.rD + k_off(tok, d, a.rD)] = oh;
+                            else
+                                vpool[((int64_t)page * a.rHkv + (head - a.rH - a.rHkv)) * 32 * a.rD + (int64_t)d * 32 +
+                                      v_col(tok)] = oh;
+                        }
+                    }
+                }
+            return;
+        }
+        const int n = nt * 32 + c;
+        if (ACT == 2) {
+            const int half = a.N >> 1;
+            const int j2 = nt * 16 + (c & 15);
+            const int nsrc = (c < 16) ? j2 : half + j2;
+            const float bv = (a.bias && j2 < half) ? to_f32(reinterpret_cast<const T*>(a.bias)[nsrc]) : 0.f;
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const float mine = to_f32(from_f32<T>(fin[mr][j] + bv));
+                    const float other = __shfl_xor(mine, 16, 64);
+                    const int m = mr * 32 + row_of(j);
+                    if (c < 16 && j2 < half && m < mrows) {
+                        float sl = mine / (1.f + __expf(-mine));
+                        reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + j2] =
+                            from_f32<T>(to_f32(from_f32<T>(sl)) * other);
+                    }
+                }
+            return;
+        }
+        if (a.S == 1 && !a.partial) {
+            if (n >= a.N) return;
+            const float bv = a.bias ? to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int m = mr * 32 + row_of(j);
+                    if (m >= mrows) continue;
+                    if (a.out_f32)
+                        reinterpret_cast<float*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = fin[mr][j] + bv;
+                    else
+                        reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = from_f32<T>(fin[mr][j] + bv);
+                }
+        } else {
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+                float* sl = a.slabs + ((int64_t)((mslab * MR + mr) * a.S + split) * 32) * (a.NT * 32) + n;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) sl[(int64_t)row_of(j) * (a.NT * 32)] = fin[mr][j];
+            }
+        }
+        return;
+    }
     if (WK > 1) {
         float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][MR][64 lanes][16]
         if (wk > 0) {

@@ -16,7 +16,8 @@ namespace {
 // matching up rows in columns 16..31, so that the ACT = 2 epilogue finds each (gate, up) pair inside one wave.
 template <typename T>
 __global__ void dense_prepare_kernel(const T* __restrict__ w, T* __restrict__ out, int64_t N, int64_t K,
-                                     int64_t NT, int64_t KS, int gate_up) {
+                                     int64_t NT, int64_t KS, int flags) {
+    const int gate_up = flags & 1;
     using V8 = typename VecT<T>::x8;
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk each
     if (idx >= NT * KS * 256) return;
@@ -28,6 +29,12 @@ __global__ void dense_prepare_kernel(const T* __restrict__ w, T* __restrict__ ou
     if (gate_up) {
         const int64_t half = N >> 1, j = nt * 16 + (l & 15);
         n = j < half ? ((l & 31) < 16 ? j : half + j) : N;  // past the last pair: a zero column
+    } else if (flags & 2) {
+        // rope image of a fused qkv projection (head size D in bits 8..19, rotated heads H + Hkv in bits 20..31): a tile of
+        // a rotated head holds dims [16 t, 16 t + 16) in columns 0-15 and their rotation partners D/2 + [16 t, ..) in 16-31
+        const int D = (flags >> 8) & 0xFFF, nrot = (flags >> 20) & 0xFFF, per = D >> 5, c = l & 31;
+        const int64_t head = nt / per, t = nt - head * per;
+        if (head < nrot) n = head * D + ((c < 16) ? 16 * t + c : (D >> 1) + 16 * t + (c - 16));
     }
     int64_t k = (ks * 8 + (l >> 5) * 4 + i) * 8;
     V8 v;
@@ -112,7 +119,8 @@ static int launch_dense(const DenseArgs& a, const DensePlan& pl, int act, int64_
     int rc = TGIS_EINVAL;
 #define TGIS_DENSE_CASE(T_, W_)                                                        \
     if (pl.TN == T_ && pl.WK == W_)                                                    \
-        rc = act == 2   ? launch_dense_variant<T, T_, W_, 2>(pl.MR, grid, lds, st, a)                                           \
+        rc = act == 3   ? launch_dense_variant<T, T_, W_, 3>(pl.MR, grid, lds, st, a)                                           \
+             : act == 2 ? launch_dense_variant<T, T_, W_, 2>(pl.MR, grid, lds, st, a)                                           \
              : act == 1 ? launch_dense_variant<T, T_, W_, 1>(pl.MR, grid, lds, st, a)                                           \
                         : launch_dense_variant<T, T_, W_, 0>(pl.MR, grid, lds, st, a)
     TGIS_DENSE_CASE(2, 2);
@@ -149,15 +157,21 @@ extern "C" int tgis_dense_prepare(const void* w, int64_t N, int64_t K, int dtype
     TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "tgis_dense_prepare: bad dtype");
     const int gate_up = flags & 1;
     TGIS_CHECK_ARG(!gate_up || N % 32 == 0, "tgis_dense_prepare: the gate|up image needs N / 2 to be a multiple of 16");
+    if (flags & 2) {
+        const int D = (flags >> 8) & 0xFFF, nrot = (flags >> 20) & 0xFFF;
+        TGIS_CHECK_ARG(!gate_up && D >= 32 && D % 32 == 0 && nrot >= 1 && (int64_t)nrot * D <= N && N % D == 0,
+                       "tgis_dense_prepare: rope image needs head size %% 32 == 0 and rotated heads within N (D=%d, heads=%d)",
+                       D, nrot);
+    }
     int64_t NT = cdiv64(N, 32), KS = cdiv64(K, 64);
     int64_t total = NT * KS * 256;
     dim3 grid((unsigned)cdiv64(total, 256));
     if (dtype == TGIS_F16)
         hipLaunchKernelGGL(dense_prepare_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)w,
-                           (f16*)prepared, N, K, NT, KS, gate_up);
+                           (f16*)prepared, N, K, NT, KS, flags);
     else
         hipLaunchKernelGGL(dense_prepare_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)w,
-                           (bf16*)prepared, N, K, NT, KS, gate_up);
+                           (bf16*)prepared, N, K, NT, KS, flags);
     TGIS_CHECK_LAUNCH();
     return TGIS_OK;
 }
@@ -199,6 +213,10 @@ static void dense_fill(DenseArgs& a, const void* x, int64_t ldx, const void* pre
     a.slabs = slabs;
     a.partial = partial;
     a.err = nullptr;
+    a.positions = a.slots = nullptr;
+    a.cosb = a.sinb = nullptr;
+    a.kpool = a.vpool = nullptr;
+    a.rH = a.rHkv = a.rD = 0;
 }
 
 extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared, const void* bias, void* out,
@@ -219,6 +237,43 @@ extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared,
     dense_fill(a, x, ldx, prepared, bias, out, ldo, M, K, N, out_f32, (float*)((uint8_t*)workspace + 4096), 0, pl);
     return dtype == TGIS_F16 ? launch_dense<f16>(a, pl, act, cdiv64(M, 32), st)
                              : launch_dense<bf16>(a, pl, act, cdiv64(M, 32), st);
+}
+
+// ---- qkv projection with the rotary embedding and the cache write in its epilogue (dense weights) ---------------------
+extern "C" int tgis_dense_rope_ok(int64_t M, int64_t K, int64_t N, int64_t D) {
+    if (M < 1 || M > 64 || D < 32 || D % 32 || N <= 0 || N % D || K <= 0 || K % 8) return 0;
+    // as tgis_gptq_rope_ok: the unsplit plan must still cover the chip, or the matrix be launch-bound anyway
+    const DensePlan pl = plan_dense(K, N, M, 2);
+    const int64_t blocks = cdiv64(cdiv64(N, 32), pl.TN);
+    return (blocks >= 128 || K * N * 2 <= (12 << 20)) ? 1 : 0;
+}
+
+extern "C" int tgis_dense_gemm_rope(const void* x, int64_t ldx, const void* prepared, const void* bias,
+                                    const int32_t* positions, const int32_t* slots, const void* cos, const void* sin,
+                                    void* q_out, int64_t ldq, void* k_pool, void* v_pool, int64_t M, int64_t K, int64_t N,
+                                    int64_t H, int64_t Hkv, int64_t D, int dtype, void* stream) {
+    int rc = dense_check(x, ldx, prepared, M, K, N, dtype, 0);
+    if (rc != TGIS_OK) return rc;
+    TGIS_CHECK_ARG(positions && slots && cos && sin && q_out && k_pool && v_pool, "tgis_dense_gemm_rope: null tensor");
+    TGIS_CHECK_ARG(M >= 1 && M <= 64 && D >= 32 && D % 32 == 0, "tgis_dense_gemm_rope: needs 1 <= M <= 64 and a head size "
+                   "that is a multiple of 32 (M=%ld D=%ld)", (long)M, (long)D);
+    TGIS_CHECK_ARG(H >= 1 && Hkv >= 1 && (H + 2 * Hkv) * D == N && ldq >= H * D,
+                   "tgis_dense_gemm_rope: N must be (H + 2 Hkv) * D and q rows must hold H * D elements");
+    hipStream_t st = (hipStream_t)stream;
+    DensePlan pl = plan_dense(K, N, M, 2);  // as the SiLU epilogue: the whole k range in one block (S == 1)
+    TgisTimedScope timed(TGIS_OP_DENSE_GEMM, st);
+    DenseArgs a;
+    dense_fill(a, x, ldx, prepared, bias, q_out, ldq, M, K, N, 0, nullptr, 0, pl);
+    a.positions = positions;
+    a.slots = slots;
+    a.cosb = cos;
+    a.sinb = sin;
+    a.kpool = k_pool;
+    a.vpool = v_pool;
+    a.rH = (int)H;
+    a.rHkv = (int)Hkv;
+    a.rD = (int)D;
+    return dtype == TGIS_F16 ? launch_dense<f16>(a, pl, 3, cdiv64(M, 32), st) : launch_dense<bf16>(a, pl, 3, cdiv64(M, 32), st);
 }
 
 extern "C" int64_t tgis_dense_gemm_partial_bytes(int64_t M, int64_t K, int64_t N) {

@@ -154,7 +154,7 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
                                                unsigned char* smem, const int ub_base, WeightRing<RING>& ring) {
     static_assert(MR == 1 || WK == 2, "64-row passes need the LDS of two k-parts");
     static_assert(!TAIL || (MR == 1 && !PERM && ACT != 1 && ACT != 3), "the decode tail runs 32-row, un-permuted units");
-    static_assert(ACT != 3 || (MR == 1 && !PERM), "the rope epilogue is a decode form (<= 32 rows, no act-order)");
+    static_assert(ACT != 3 || !PERM, "the rope epilogue is a decode form (<= 64 rows, no act-order)");
     static_assert(RING == 4 || RING == 8, "one or two chunks of weights in flight");
     static_assert(MODE == UNIT_FULL || GROUP64, "a pre-filled ring carries the scales of GROUP64 images");
     constexpr int NWAVES = TN * WK;
@@ -214,15 +214,17 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
     }
 
     // ACT 3: cache slot and rotary position of the rows this wave will finish (see the distributed epilogue)
-    int32_t rpos[ACT == 3 ? 16 / WK : 1], rslot[ACT == 3 ? 16 / WK : 1];
+    int32_t rpos[ACT == 3 ? MR : 1][ACT == 3 ? 16 / WK : 1], rslot[ACT == 3 ? MR : 1][ACT == 3 ? 16 / WK : 1];
     if (ACT == 3) {
 #pragma unroll
-        for (int j = 0; j < 16 / WK; ++j) {
-            const int r = wk * (16 / WK) + j;
-            const int m = min((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), mrows - 1);
-            rpos[j] = a.positions[m0 + m];
-            rslot[j] = a.slots[m0 + m];
-        }
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int j = 0; j < 16 / WK; ++j) {
+                const int r = wk * (16 / WK) + j;
+                const int m = min(mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), mrows - 1);
+                rpos[mr][j] = a.positions[m0 + m];
+                rslot[mr][j] = a.slots[m0 + m];
+            }
     }
 
     // ---- x staging: local thread t handles rows (t / 32) + RSTEP j, 16-byte column piece (t & 31) ----
@@ -487,17 +489,19 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
     // its tile, i.e. NR of the 16 row groups.  ACT 3: it asks for those rows' cos / sin entries now (the positions were
     // loaded at entry), so that the round trip runs under the k-part exchange.
     constexpr int NR = 16 / WK;
-    f16 rcos[MR == 1 ? NR : 1], rsin[MR == 1 ? NR : 1];
+    f16 rcos[ACT == 3 ? MR : 1][ACT == 3 ? NR : 1], rsin[ACT == 3 ? MR : 1][ACT == 3 ? NR : 1];
     if (ACT == 3) {
         const int per = a.rD >> 5;
         const int tt = nt - (nt / per) * per;
         const int dr = 16 * tt + (lane & 15);
         const bool roth = nt / per < a.rH + a.rHkv;
 #pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            rcos[j] = roth ? a.cosb[(int64_t)rpos[j] * (a.rD >> 1) + dr] : (f16)1.f;
-            rsin[j] = roth ? a.sinb[(int64_t)rpos[j] * (a.rD >> 1) + dr] : (f16)0.f;
-        }
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                rcos[mr][j] = roth ? a.cosb[(int64_t)rpos[mr][j] * (a.rD >> 1) + dr] : (f16)1.f;
+                rsin[mr][j] = roth ? a.sinb[(int64_t)rpos[mr][j] * (a.rD >> 1) + dr] : (f16)0.f;
+            }
     }
     unit_barrier();  // every k-part is done with its x buffers: the reduction below reuses them
 
@@ -559,13 +563,15 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
             const int col = head * a.rD + d;
             const float bv = a.bias ? (float)a.bias[col] : 0.f;
 #pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
             for (int j = 0; j < NR; ++j) {
-                const int m = row_of(j);
-                const float mine = (float)(f16)(fin[0][j] + bv);
+                const int m = mr * 32 + row_of(j);
+                const float mine = (float)(f16)(fin[mr][j] + bv);
                 float o = mine;
                 if (roth) {
                     const float other = __shfl_xor(mine, 16, 64);
-                    const float cf = (float)rcos[j], sf = (float)rsin[j];
+                    const float cf = (float)rcos[mr][j], sf = (float)rsin[mr][j];
                     o = (c < 16) ? mine * cf - other * sf : other * sf + mine * cf;
                 }
                 const f16 oh = (f16)o;
@@ -573,7 +579,7 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
                     if (head < a.rH) {
                         a.out[(int64_t)(m0 + m) * a.ldo + col] = oh;
                     } else {
-                        const int page = rslot[j] >> 5, tok = rslot[j] & 31;
+                        const int page = rslot[mr][j] >> 5, tok = rslot[mr][j] & 31;
                         if (roth)
                             a.kpool[((int64_t)page * a.rHkv + (head - a.rH)) * 32 * a.rD + k_off(tok, d, a.rD)] = oh;
                         else

@@ -148,10 +148,11 @@ class FlashLlamaAttention:
         lin = self.query_key_value.linear
         rope_w = getattr(lin, "rope_handle", None)
         if (rope_w is not None and kv.slots is not None and not kv.fresh_prefill and kv.max_q_len == 1
-                and hidden_states.shape[0] <= 32 and cos.shape[1] * 2 == D):
-            # one launch: GEMM + rotary embedding + cache write (native.gptq_gemm_rope)
-            return native.gptq_gemm_rope(hidden_states, rope_w, lin.bias, cos, sin, position_ids, kv.slots, k_pool, v_pool,
-                                         H, Hkv, D)
+                and hidden_states.shape[0] <= 64 and cos.shape[1] * 2 == D
+                and native.rope_gemm_ok(hidden_states.shape[0], rope_w, D)):
+            # one launch: GEMM + rotary embedding + cache write (native.gptq_gemm_rope / native.dense_gemm_rope)
+            fused = native.gptq_gemm_rope if isinstance(rope_w, native.GptqWeight) else native.dense_gemm_rope
+            return fused(hidden_states, rope_w, lin.bias, cos, sin, position_ids, kv.slots, k_pool, v_pool, H, Hkv, D)
         # [T, (H + 2 Hkv) D]; at decode sizes the split-K sum of the GPTQ GEMM is finished inside the rope kernel
         qkv = self.query_key_value(hidden_states, partial=True)
         if kv.fresh_prefill and not isinstance(qkv, native.Partial):

@@ -62,7 +62,10 @@ SIGNATURES = {
     "tgis_gptq_gemm_f16_partial": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_i64,
                                             ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64), _vp]),
     "tgis_gptq_dequant_f16": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp]),
-    "tgis_gptq_rope_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_int, _c_i64]),
+    "tgis_dense_gemm_rope": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_i64,
+                                      _c_i64, _c_i64, _c_i64, _c_int, _vp]),
+    "tgis_gptq_rope_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_i64]),
+    "tgis_dense_rope_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64]),
     "tgis_gptq_gemm_rope_f16": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _c_i64,
                                          _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp]),
     "tgis_gptq_lean_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int]),
@@ -336,12 +339,26 @@ def gptq_gemm_partial(x: torch.Tensor, w: GptqWeight, bias=None, act: int = 0) -
 
 
 def gptq_rope_ok(M: int, w: GptqWeight, D: int) -> bool:
-    return bool(load_library().tgis_gptq_rope_ok(M, w.K, w.groups, int(w.perm is not None), D))
+    return bool(load_library().tgis_gptq_rope_ok(M, w.K, w.N, w.groups, int(w.perm is not None), D))
+
+
+def rope_gemm_ok(M: int, w, D: int) -> bool:
+    """Whether the fused qkv + rotary + cache-write launch should serve M rows of this weight (int4 or dense image)."""
+    key = ("rope_ok", M)
+    cache = w.__dict__.setdefault("_rope_ok", {})
+    got = cache.get(key)
+    if got is None:
+        if isinstance(w, GptqWeight):
+            got = gptq_rope_ok(M, w, D)
+        else:
+            got = bool(load_library().tgis_dense_rope_ok(M, w.K, w.N, D))
+        cache[key] = got
+    return got
 
 
 def gptq_gemm_rope(x: torch.Tensor, w: GptqWeight, bias, cos, sin, positions, slots, k_pool, v_pool, H: int, Hkv: int,
                    D: int, out=None) -> torch.Tensor:
-    """qkv projection + rotary embedding + cache write in one launch (decode, M <= 32; `w` is the rope image of the fused
+    """qkv projection + rotary embedding + cache write in one launch (decode, M <= 64; `w` is the rope image of the fused
     qkv weight).  Returns a [M, (H + 2 Hkv) D] tensor whose first H D columns hold the rotated q (the k / v columns are not
     written: they went straight into their cache pages)."""
     assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == w.K
@@ -441,12 +458,15 @@ class DenseWeight:
     """torch-Linear weight [N,K] repacked into MFMA tile order.  gate_up=True: the weight is the Llama MLP's
     [gate | up] and the image interleaves the pairs for the SiLU*up epilogue (dense_gemm(act=2))."""
 
-    def __init__(self, weight: torch.Tensor, gate_up: bool = False):
+    def __init__(self, weight: torch.Tensor, gate_up: bool = False, rope: Optional[tuple] = None):
         lib = load_library()
         assert weight.dim() == 2
         self.N, self.K = weight.shape
         self.dtype = weight.dtype
         self.flags = 1 if gate_up else 0
+        if rope is not None:  # (D, rotated heads): the image of a fused qkv projection for dense_gemm_rope
+            assert not gate_up
+            self.flags = 2 | (int(rope[0]) << 8) | (int(rope[1]) << 20)
         weight = weight.contiguous()
         self.image = torch.empty(lib.tgis_dense_prepared_bytes(self.N, self.K), dtype=torch.uint8,
                                  device=weight.device)
@@ -490,6 +510,24 @@ def dense_gemm_partial(x: torch.Tensor, w: DenseWeight, bias=None, act: int = 0)
     p = Partial(slabs, S.value, ld.value, x.shape[0], w.N, bias)
     p.dtype = w.dtype
     return p
+
+
+def dense_gemm_rope(x: torch.Tensor, w: DenseWeight, bias, cos, sin, positions, slots, k_pool, v_pool, H: int, Hkv: int,
+                    D: int, out=None) -> torch.Tensor:
+    """Dense qkv projection + rotary embedding + cache write in one launch (decode, M <= 64; `w` is the rope image of the
+    fused qkv weight).  Returns [M, (H + 2 Hkv) D] whose first H D columns hold the rotated q."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == w.dtype and x.shape[1] == w.K
+    assert w.flags & 2 and w.N == (H + 2 * Hkv) * D and cos.dtype == w.dtype and cos.shape[1] * 2 == D
+    assert positions.dtype == torch.int32 and slots.dtype == torch.int32
+    M = x.shape[0]
+    if out is None:
+        out = torch.empty((M, w.N), dtype=w.dtype, device=x.device)
+    _check(
+        load_library().tgis_dense_gemm_rope(_ptr(x), x.stride(0), _ptr(w.image), _ptr(bias), _ptr(positions), _ptr(slots),
+                                            _ptr(cos), _ptr(sin), _ptr(out), out.stride(0), _ptr(k_pool), _ptr(v_pool), M,
+                                            w.K, w.N, H, Hkv, D, dtype_code(w.dtype), _stream()),
+        "tgis_dense_gemm_rope")
+    return out
 
 
 def clear_error() -> None:

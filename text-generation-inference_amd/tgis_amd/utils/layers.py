@@ -46,6 +46,8 @@ class FastLinear:
         self.prepared = native.DenseWeight(weight)
         self.out_features, self.in_features = weight.shape
         self._gate_up = False
+        self._rope_heads = None
+        self.rope_handle: Optional[native.DenseWeight] = None
 
     @property
     def gate_up(self) -> bool:
@@ -58,6 +60,19 @@ class FastLinear:
         if bool(on) != self._gate_up:
             self._gate_up = bool(on)
             self.prepared = native.DenseWeight(self.weight, gate_up=self._gate_up)
+
+    @property
+    def rope_heads(self):
+        return self._rope_heads
+
+    @rope_heads.setter
+    def rope_heads(self, heads):
+        """Set by FlashLlamaAttention on the fused qkv projection: (H, Hkv, D) of this shard.  Builds the rope image (a
+        second copy of the weight with rotation pairs inside each tile) for native.dense_gemm_rope."""
+        self._rope_heads = heads
+        if heads is not None and FUSED_ROPE_GEMM and heads[2] % 32 == 0:
+            H, Hkv, D = heads
+            self.rope_handle = native.DenseWeight(self.weight, rope=(D, H + Hkv))
 
     def forward(self, x: torch.Tensor, act: int = 0, out_f32: bool = False, partial: bool = False) -> torch.Tensor:
         if self._gate_up:
@@ -109,7 +124,7 @@ class Ex4bitLinearV2:
                                           self.groupsize, gate_up=self.gate_up)
         if self.rope_heads is not None and FUSED_ROPE_GEMM:
             H, Hkv, D = self.rope_heads
-            if self.q_handle.perm is None and native.gptq_rope_ok(1, self.q_handle, D):
+            if self.q_handle.perm is None and any(native.gptq_rope_ok(m, self.q_handle, D) for m in (1, 32, 64)):
                 self.rope_handle = native.GptqWeight(self.qweight, self.qzeros, self.scales, None, self.bits,
                                                      self.groupsize, rope=(D, H + Hkv))
         self.qweight = self.qzeros = self.scales = None  # the prepared image replaces them
