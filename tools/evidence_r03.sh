@@ -12,3 +12,4 @@ for s in "4096 12288 0" "4096 22016 2"; do TGIS_LEAN_LD=1 python tools/trace_ld.
 ./tools/floor/lean > $O/r03_lean_step.log 2>&1
 ./tools/floor/ldsdma > $O/r03_ldsdma.log 2>&1
 cut -c1-200 $O/r03_bench_cfg2.json $O/r03_bench_cfg5.json $O/r03_bench_cfg4_1gpu.json
+(export TGIS_LEAN_LD=0; echo "# lean register-ring kernel, us per launch (qkv / o / gate_up / down); LEAN_ABL bits: 1 no correction MFMA + fold, 2 no row-sum staging, 4 no x loads, 8 no x stores + chunk syncs, 16 no weight refills, 32 no arithmetic"; echo "== full"; python tools/lean_gemm.py 32 time 2>&1 | grep -v amdgpu.ids | sed "s/old.*lean/lean/"; for a in 3 6 14 30 32 46 62; do echo "== LEAN_ABL=$a"; TGIS_HIP_LIB=$PWD/text-generation-inference_amd/lib/lean_abl$a.so python tools/lean_gemm.py 32 time 2>&1 | grep -v amdgpu.ids | sed "s/old.*lean/lean/"; done) > $O/r03_lean_ablations.log
