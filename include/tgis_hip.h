@@ -132,6 +132,38 @@ int tgis_gptq_gemm_rope_f16(const void* x, int64_t ldx, const void* prepared, co
                             void* k_pool, void* v_pool, int64_t M, int64_t K, int64_t N, int64_t groups, int64_t H,
                             int64_t Hkv, int64_t D, void* stream);
 
+/* ---- add + RMSNorm as the FIRST PHASE of the GEMM behind it (decode, <= 32 rows, round 3) ----------------------------
+ * `LlamaRMSNorm.forward` (flash_llama_modeling.py:132-152) followed by `gate_up_proj` + SiLU * up (:332-335), resp. by
+ * `query_key_value` + rotary embedding + cache write (:251-268,282), as ONE launch: workgroup r normalises row r (the
+ * arithmetic of tgis_rmsnorm_residual[_partial], bit for bit), all workgroups meet at a grid barrier while their weight
+ * rings are already streaming, and the GEMM phase reads the normed rows with L1-bypassing loads.  `norm` describes the norm:
+ * its input either as `x` or as the split-K `slabs` of the GEMM before (+ `slab_bias`), `residual` (may be NULL), `weight`,
+ * `eps`, and its two outputs `y` (the normed activation [M, K]: also the GEMM's operand) and `res_out` (the residual stream).
+ * Needs every workgroup of the launch resident at once: tgis_gptq_norm_gemm_ok says whether the shape qualifies on this
+ * device (unsplit plan with M <= blocks <= CUs; not when TGIS_ALLOW_SHARED_GPU marks the GPU as shared between processes)
+ * and allocates the library-owned barrier — call it once outside any stream capture.  All waits are bounded:
+ * tgis_gptq_norm_gemm_status returns a give-up code (0 = none). */
+typedef struct tgis_norm_in {
+    const float* slabs;     /* [ceil(M/32)][num_slabs][32][slab_ld] fp32, or NULL */
+    int num_slabs;
+    int64_t slab_ld;
+    const void* slab_bias;  /* bias of the GEMM that left the slabs, or NULL */
+    const void* x;          /* f16 [M, K] when slabs == NULL */
+    const void* residual;   /* f16 [M, K] or NULL */
+    const void* weight;     /* f16 [K] */
+    float eps;
+    void* y;                /* f16 [M, K] out */
+    void* res_out;          /* f16 [M, K] out */
+} tgis_norm_in;
+int tgis_gptq_norm_gemm_ok(int64_t M, int64_t K, int64_t N, int64_t groups, int act_order, int act);
+int tgis_gptq_norm_gemm_status(int reset);
+int tgis_gptq_norm_gate_up_f16(const tgis_norm_in* norm, const void* prepared, const void* bias, void* out, int64_t ldo,
+                               int64_t M, int64_t K, int64_t N, int64_t groups, void* stream);
+int tgis_gptq_norm_qkv_rope_f16(const tgis_norm_in* norm, const void* prepared, const void* bias, const int32_t* positions,
+                                const int32_t* slots, const void* cos, const void* sin, void* q_out, int64_t ldq,
+                                void* k_pool, void* v_pool, int64_t M, int64_t K, int64_t N, int64_t groups, int64_t H,
+                                int64_t Hkv, int64_t D, void* stream);
+
 /* The same launch for dense (f16 / bf16) qkv weights: `prepared` from tgis_dense_prepare with
  * flags = TGIS_GPTQ_ROPE_IMAGE(D, H + Hkv); cos / sin in the model dtype; 1 <= M <= 64. */
 int tgis_dense_rope_ok(int64_t M, int64_t K, int64_t N, int64_t D);

@@ -167,6 +167,7 @@ def install(monkeypatch):
         gptq_gemm_partial=lambda x, w, bias=None, act=0: _gptq_gemm(x, w, None, bias=bias, act=act),
         gptq_rope_ok=lambda M, w, D: 1 <= M <= 64 and w.perm is None,
         rope_gemm_ok=lambda M, w, D: 1 <= M <= 64 and getattr(w, "perm", None) is None,
+        gptq_norm_gemm_ok=lambda M, w, act: False,  # (a grid barrier has no CPU stand-in: the two launches run)
         dense_gemm_rope=lambda x, w, bias, cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, out=None: _rope_kv_write(
             _dense_gemm(x, w, None, bias=bias), cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, D),
         gptq_gemm_rope=lambda x, w, bias, cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, out=None: _rope_kv_write(

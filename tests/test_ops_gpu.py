@@ -520,6 +520,51 @@ def test_gptq_gemm_rope_equals_gemm_then_rope_kv_write(nat, gpu_device, H, Hkv, 
         assert float(Kp[free].abs().sum()) == 0 and float(Vp[free].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("B,partial,resid", [(32, True, True), (7, True, True), (1, False, True), (32, False, False)])
+def test_norm_phase_gemms_are_bit_identical_to_the_separate_launches(nat, gpu_device, B, partial, resid):
+    """tgis_gptq_norm_gate_up_f16 / tgis_gptq_norm_qkv_rope_f16 (add + RMSNorm as the first phase of the GEMM launch: norm
+    rows -> grid barrier -> GEMM on L1-bypassing loads) against tgis_rmsnorm_residual[_partial] followed by the plain
+    launches: the same arithmetic in the same order, so activation, residual stream, q and cache pages must be
+    BIT-identical — a stale line read after the barrier would show up as a difference.  Repeated on re-used buffers."""
+    K, I, H, Hkv, D = 4096, 11008, 32, 32, 128
+    g = torch.Generator().manual_seed(B + 3)
+    qw, qz, sc, gi = ops_ref.make_gptq_tensors(K, 2 * I, 128, seed=5)
+    t = [torch.from_numpy(a).to(gpu_device) for a in (qw, qz, sc)]
+    w_gu = nat.GptqWeight(t[0], t[1], t[2], None, 4, 128, gate_up=True)
+    qw2, qz2, sc2, _ = ops_ref.make_gptq_tensors(K, (H + 2 * Hkv) * D, 128, seed=6)
+    t2 = [torch.from_numpy(a).to(gpu_device) for a in (qw2, qz2, sc2)]
+    w_qkv = nat.GptqWeight(t2[0], t2[1], t2[2], None, 4, 128, rope=(D, H + Hkv))
+    if not (nat.gptq_norm_gemm_ok(B, w_gu, 2) and nat.gptq_norm_gemm_ok(B, w_qkv, 3)):
+        pytest.skip("the two-phase launch is not available here (shared GPU or too few CUs)")
+    qw3, qz3, sc3, _ = ops_ref.make_gptq_tensors(K, K, 128, seed=7)  # a GEMM that leaves split-K slabs in front of the norm
+    w_prev = nat.GptqWeight(*[torch.from_numpy(a).to(gpu_device) for a in (qw3, qz3, sc3)], None, 4, 128)
+    wn = (torch.rand(K, generator=g) + 0.5).half().to(gpu_device)
+    cos, sin = ops_ref.rope_tables(D, 10000.0, 128, torch.float16)
+    cos, sin = cos.to(gpu_device), sin.to(gpu_device)
+    ws = nat.Workspace(w_gu.workspace_bytes(B), gpu_device)
+    pools = [torch.zeros((8, Hkv, 32 * D), dtype=torch.float16, device=gpu_device) for _ in range(4)]
+    for rep in range(6):
+        xin = (torch.randn(B, K, generator=g) * 0.5).half().to(gpu_device)
+        res = (torch.randn(B, K, generator=g)).half().to(gpu_device) if resid else None
+        pos = torch.randint(0, 128, (B,), generator=g).int().to(gpu_device)
+        slots = torch.randperm(8 * 32, generator=g)[:B].int().to(gpu_device)
+
+        def src():
+            return nat.gptq_gemm_partial(xin, w_prev) if partial else xin.clone()
+
+        y0, r0 = nat.rmsnorm_residual(src(), res, wn, 1e-5)
+        a0 = nat.gptq_gemm(y0, w_gu, ws, act=2)
+        a1, r1 = nat.gptq_norm_gate_up(src(), res, wn, 1e-5, w_gu)
+        assert torch.equal(r0, r1), f"residual rep {rep}: {int((r0 != r1).sum())} elements differ"
+        assert torch.equal(a0, a1), (f"gate_up rep {rep}: {int((a0 != a1).sum())} of {a0.numel()} elements differ, max "
+                                     f"{float((a0.float() - a1.float()).abs().max())}, rows {sorted(set((a0 != a1).nonzero()[:, 0].tolist()))[:40]}")
+        q0 = nat.gptq_gemm_rope(y0, w_qkv, None, cos, sin, pos, slots, pools[0], pools[1], H, Hkv, D)
+        q1, r2 = nat.gptq_norm_qkv_rope(src(), res, wn, 1e-5, w_qkv, None, cos, sin, pos, slots, pools[2], pools[3], H, Hkv, D)
+        assert torch.equal(q0[:, :H * D], q1[:, :H * D]) and torch.equal(r0, r2), f"qkv rep {rep}"
+        assert torch.equal(pools[0], pools[2]) and torch.equal(pools[1], pools[3]), f"cache pages rep {rep}"
+    assert nat.gptq_norm_gemm_status() == 0, "a bounded wait of the two-phase launch gave up"
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("H,Hkv,D,K,B,bias", [(32, 4, 64, 2048, 16, False), (8, 8, 128, 1024, 7, True), (32, 4, 64, 2048, 40, False),
                                               (4, 1, 32, 256, 1, True)])

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <numeric>
 #include <vector>
+#include <mutex>
 #include "common.h"
 #include <type_traits>
 #include "gptq_gemm_body.h"
@@ -96,12 +97,12 @@ __global__ void gptq_prepare_sz_kernel(const int32_t* __restrict__ qzeros, const
     sz[idx] = __builtin_bit_cast(uint32_t, v);
 }
 
-template <int TN, int WK, int ACT, bool GROUP64, bool PERM, int MR>
+template <int TN, int WK, int ACT, bool GROUP64, bool PERM, int MR, bool NORMP = false>
 __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     gptq::WeightRing<4> ring;
-    gptq::gptq_gemm_unit<TN, WK, ACT, GROUP64, PERM, MR, false, 4, gptq::UNIT_FULL>(a, blockIdx.x, blockIdx.y, blockIdx.z,
-                                                                                    smem, 0, ring);
+    gptq::gptq_gemm_unit<TN, WK, ACT, GROUP64, PERM, MR, false, 4, gptq::UNIT_FULL, NORMP>(a, blockIdx.x, blockIdx.y,
+                                                                                           blockIdx.z, smem, 0, ring);
 }
 
 // ---- "tall" kernel: 64 < M (decode batches beyond 32 rows, add-on prefills of up to a few thousand tokens) --------
@@ -518,6 +519,8 @@ static int launch_tall(const void* x, int64_t ldx, const void* prepared, const v
     a.cosb = a.sinb = nullptr;
     a.kpool = a.vpool = nullptr;
     a.rH = a.rHkv = a.rD = 0;
+    a.norm = gsync::NormPhase{};
+    a.bar = nullptr;
     if (groups > 1)
         for (a.spg_shift = 0; (1 << a.spg_shift) < spg; ++a.spg_shift) {}
     const int BM = 32 * tp.BMR;
@@ -566,16 +569,28 @@ extern "C" int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t 
     return need;
 }
 
-template <int TN, int WK, int ACT, bool G64, bool PERM, int MR>
+template <int TN, int WK, int ACT, bool G64, bool PERM, int MR, bool NORMP = false>
 static int launch_one(dim3 grid, size_t lds, hipStream_t st, const GemmArgs& a) {
     static bool attr_done = false;
     if (!attr_done) {
-        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_gemm_kernel<TN, WK, ACT, G64, PERM, MR>,
+        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_gemm_kernel<TN, WK, ACT, G64, PERM, MR, NORMP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * RS * 2 + 64));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gptq_gemm_kernel<TN, WK, ACT, G64, PERM, MR>), grid, dim3(64 * TN * WK), lds, st, a);
+    hipLaunchKernelGGL((gptq_gemm_kernel<TN, WK, ACT, G64, PERM, MR, NORMP>), grid, dim3(64 * TN * WK), lds, st, a);
     return TGIS_OK;
+}
+// the unit with the add + RMSNorm in front of it as its first phase (32-row gate_up / qkv + rope units)
+template <int ACT>
+static int launch_normp(const GemmPlan& pl, dim3 grid, size_t lds, hipStream_t st, const GemmArgs& a) {
+    switch (pl.TN * 10 + pl.WK) {
+        case 44: return launch_one<4, 4, ACT, true, false, 1, true>(grid, lds, st, a);
+        case 42: return launch_one<4, 2, ACT, true, false, 1, true>(grid, lds, st, a);
+        case 34: return launch_one<3, 4, ACT, true, false, 1, true>(grid, lds, st, a);
+        case 32: return launch_one<3, 2, ACT, true, false, 1, true>(grid, lds, st, a);
+        case 24: return launch_one<2, 4, ACT, true, false, 1, true>(grid, lds, st, a);
+        default: return launch_one<2, 2, ACT, true, false, 1, true>(grid, lds, st, a);
+    }
 }
 template <int TN, int WK, int ACT, bool G64, bool PERM>
 static int launch_variant(int mr, dim3 grid, size_t lds, hipStream_t st, const GemmArgs& a) {
@@ -594,7 +609,8 @@ struct RopeEpi {
 
 static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const void* bias, const int32_t* perm,
                        void* out, int64_t ldo, int64_t M, int64_t K, int64_t N, int64_t groups, int act, float* slabs,
-                       int partial, const GemmPlan& pl, hipStream_t st, const RopeEpi* rope = nullptr) {
+                       int partial, const GemmPlan& pl, hipStream_t st, const RopeEpi* rope = nullptr,
+                       const gsync::NormPhase* norm = nullptr, gsync::GridBar* bar = nullptr) {
     PrepLayout p = prep_layout(K, N, groups);
     const int64_t mslabs = cdiv64(M, 32 * pl.MR);  // passes over the weights
     const int64_t gs = K / groups;
@@ -639,8 +655,19 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
     }
     if (groups > 1 && group64)
         for (a.spg_shift = 0; (1 << a.spg_shift) < spg; ++a.spg_shift) {}
+    a.norm = gsync::NormPhase{};
+    a.bar = nullptr;
     dim3 grid((unsigned)cdiv64(p.NT, pl.TN), (unsigned)pl.S, (unsigned)mslabs);
     const size_t lds = (size_t)pl.WK * 2 * 32 * pl.MR * RS * sizeof(f16) + 64;  // x buffers + arrival counters
+    if (norm) {  // checked by the caller: act 2 / 3, group64, no permutation, <= 32 rows, S == 1, rows <= grid.x <= CUs
+        a.norm = *norm;
+        a.bar = bar;
+        a.err = &bar->err;
+        int rc_ = act == 3 ? launch_normp<3>(pl, grid, lds, st, a) : launch_normp<2>(pl, grid, lds, st, a);
+        if (rc_ != TGIS_OK) return rc_;
+        TGIS_CHECK_LAUNCH();
+        return TGIS_OK;
+    }
 #define TGIS_LAUNCH_GEMM(T, W, A, G, P)                                                        \
     do {                                                                                       \
         int rc_ = launch_variant<T, W, A, G, P>(pl.MR, grid, lds, st, a);                      \
@@ -768,6 +795,141 @@ extern "C" int tgis_gptq_gemm_rope_f16(const void* x, int64_t ldx, const void* p
     hipStream_t st = (hipStream_t)stream;
     TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
     return launch_gptq(x, ldx, prepared, bias, nullptr, q_out, ldq, M, K, N, groups, 3, nullptr, 0, pl, st, &rope);
+}
+
+// ---- add + RMSNorm as the first phase of the GEMM behind it -----------------------------------------------------------
+namespace {
+std::mutex g_gemm_bar_mu;
+gsync::GridBar* g_gemm_bar[16] = {};
+
+// The grid barrier of the two-phase launches, one per device, library-owned; allocated by the first call that is not inside
+// a stream capture (tgis_norm_gemm_ok does it too).  Launches of one device that use it must not overlap (one stream).
+gsync::GridBar* gemm_bar(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lock(g_gemm_bar_mu);
+    if (!g_gemm_bar[dev]) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (st && (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        gsync::GridBar* b = nullptr;
+        if (hipMalloc((void**)&b, sizeof(gsync::GridBar)) != hipSuccess ||
+            hipMemset(b, 0, sizeof(gsync::GridBar)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        (void)hipDeviceSynchronize();
+        g_gemm_bar[dev] = b;
+    }
+    return g_gemm_bar[dev];
+}
+
+int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+            cus = v;
+    }
+    return cus;
+}
+
+// shape conditions of the two-phase launch; *blocks receives the grid size
+bool norm_gemm_shape_ok(int64_t M, int64_t K, int64_t N, int64_t groups, int act_order, int act, int64_t* blocks) {
+    if (M < 1 || M > 32 || act_order || groups <= 0 || K % groups || (act != 2 && act != 3)) return false;
+    const int64_t gs = K / groups, spg = gs / 64;
+    if (!(groups == 1 || (gs % 64 == 0 && (spg & (spg - 1)) == 0))) return false;
+    if (K % 8 || K > 16384) return false;  // K is the hidden size the norm phase normalises
+    const GemmPlan pl = plan_gemm(K, N, 2, M);
+    const int64_t nb = cdiv64(cdiv64(N, 32), pl.TN);
+    if (blocks) *blocks = nb;
+    // every workgroup must be resident for the grid barrier (one per CU: the x buffers fill the LDS), and row r is
+    // normalised by workgroup r
+    return pl.S == 1 && nb >= M && nb <= device_cus();
+}
+
+
+int norm_phase_of(const tgis_norm_in* n, int64_t M, int64_t K, gsync::NormPhase* p) {
+    TGIS_CHECK_ARG(n && (n->slabs || n->x) && n->weight && n->y, "tgis_gptq_norm_gemm: null norm tensor");
+    TGIS_CHECK_ARG(!n->slabs || (n->num_slabs >= 1 && n->slab_ld >= K && n->slab_ld % 4 == 0),
+                   "tgis_gptq_norm_gemm: partial input needs a slab row stride >= hidden");
+    p->slabs = n->slabs;
+    p->S = n->num_slabs;
+    p->slab_ld = n->slab_ld;
+    p->xbias = n->slabs ? n->slab_bias : nullptr;
+    p->x = n->x;
+    p->residual = n->residual;
+    p->weight = n->weight;
+    p->y = n->y;
+    p->res_out = n->res_out;
+    p->rows = (int)M;
+    p->hidden = (int)K;
+    p->eps = n->eps;
+    return TGIS_OK;
+}
+}  // namespace
+
+extern "C" int tgis_gptq_norm_gemm_ok(int64_t M, int64_t K, int64_t N, int64_t groups, int act_order, int act) {
+    if (getenv("TGIS_ALLOW_SHARED_GPU")) return 0;  // several processes on one GPU: residency of a whole grid is not ours to assume
+    if (!norm_gemm_shape_ok(M, K, N, groups, act_order, act, nullptr)) return 0;
+    return gemm_bar(nullptr) ? 1 : 0;
+}
+
+extern "C" int tgis_gptq_norm_gemm_status(int reset) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !g_gemm_bar[dev]) return 0;
+    unsigned err = 0;
+    if (hipMemcpy(&err, &g_gemm_bar[dev]->err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (err && reset) (void)hipMemset(g_gemm_bar[dev], 0, sizeof(gsync::GridBar));
+    return (int)err;
+}
+
+extern "C" int tgis_gptq_norm_gate_up_f16(const tgis_norm_in* norm, const void* prepared, const void* bias, void* out,
+                                          int64_t ldo, int64_t M, int64_t K, int64_t N, int64_t groups, void* stream) {
+    gsync::NormPhase np;
+    int rc = norm_phase_of(norm, M, K, &np);
+    if (rc != TGIS_OK) return rc;
+    rc = check_gemm_args(np.y, K, prepared, M, K, N, groups, 2);
+    if (rc != TGIS_OK) return rc;
+    TGIS_CHECK_ARG(out, "tgis_gptq_norm_gate_up_f16: null out");
+    int64_t blocks = 0;
+    TGIS_CHECK_ARG(norm_gemm_shape_ok(M, K, N, groups, 0, 2, &blocks), "tgis_gptq_norm_gate_up_f16: shape not served by the "
+                   "two-phase launch (M=%ld K=%ld N=%ld groups=%ld); see tgis_gptq_norm_gemm_ok", (long)M, (long)K, (long)N,
+                   (long)groups);
+    hipStream_t st = (hipStream_t)stream;
+    gsync::GridBar* bar = gemm_bar(st);
+    TGIS_CHECK_ARG(bar, "tgis_gptq_norm_gate_up_f16: the grid barrier is allocated by the first call outside a stream capture");
+    GemmPlan pl = plan_gemm(K, N, 2, M);
+    TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
+    return launch_gptq(np.y, K, prepared, bias, nullptr, out, ldo, M, K, N, groups, 2, nullptr, 0, pl, st, nullptr, &np, bar);
+}
+
+extern "C" int tgis_gptq_norm_qkv_rope_f16(const tgis_norm_in* norm, const void* prepared, const void* bias,
+                                           const int32_t* positions, const int32_t* slots, const void* cos, const void* sin,
+                                           void* q_out, int64_t ldq, void* k_pool, void* v_pool, int64_t M, int64_t K,
+                                           int64_t N, int64_t groups, int64_t H, int64_t Hkv, int64_t D, void* stream) {
+    gsync::NormPhase np;
+    int rc = norm_phase_of(norm, M, K, &np);
+    if (rc != TGIS_OK) return rc;
+    rc = check_gemm_args(np.y, K, prepared, M, K, N, groups, 0);
+    if (rc != TGIS_OK) return rc;
+    TGIS_CHECK_ARG(positions && slots && cos && sin && q_out && k_pool && v_pool, "tgis_gptq_norm_qkv_rope_f16: null tensor");
+    TGIS_CHECK_ARG(D >= 32 && D % 32 == 0 && H >= 1 && Hkv >= 1 && (H + 2 * Hkv) * D == N && ldq >= H * D,
+                   "tgis_gptq_norm_qkv_rope_f16: N must be (H + 2 Hkv) * D, D a multiple of 32");
+    int64_t blocks = 0;
+    TGIS_CHECK_ARG(norm_gemm_shape_ok(M, K, N, groups, 0, 3, &blocks), "tgis_gptq_norm_qkv_rope_f16: shape not served by the "
+                   "two-phase launch (M=%ld K=%ld N=%ld groups=%ld); see tgis_gptq_norm_gemm_ok", (long)M, (long)K, (long)N,
+                   (long)groups);
+    hipStream_t st = (hipStream_t)stream;
+    gsync::GridBar* bar = gemm_bar(st);
+    TGIS_CHECK_ARG(bar, "tgis_gptq_norm_qkv_rope_f16: the grid barrier is allocated by the first call outside a stream capture");
+    GemmPlan pl = plan_gemm(K, N, 2, M);
+    RopeEpi rope{positions, slots, (const f16*)cos, (const f16*)sin, (f16*)k_pool, (f16*)v_pool, (int)H, (int)Hkv, (int)D};
+    TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
+    return launch_gptq(np.y, K, prepared, bias, nullptr, q_out, ldq, M, K, N, groups, 3, nullptr, 0, pl, st, &rope, &np, bar);
 }
 
 extern "C" int64_t tgis_gptq_gemm_partial_bytes(int64_t M, int64_t K, int64_t N) {

@@ -13,6 +13,7 @@
 #include <type_traits>
 #include "common.h"
 #include "kv_layout.h"
+#include "grid_sync.h"
 
 namespace gptq {
 
@@ -85,6 +86,10 @@ struct GemmArgs {
     f16* kpool;                // [pages][rHkv][32 * rD] in the K page layout of kv_layout.h
     f16* vpool;
     int rH, rHkv, rD;
+    // NORMP units (stand-alone kernel, ACT 2 / 3): the add + RMSNorm in front of this GEMM runs as its first phase — row r by
+    // workgroup r — and a grid barrier hands its output (norm.y == x) to every workgroup (grid_sync.h)
+    gsync::NormPhase norm;
+    gsync::GridBar* bar;
 };
 constexpr unsigned TAIL_SPIN_LIMIT = 1u << 24;
 
@@ -149,12 +154,14 @@ struct WeightRing {
 enum { UNIT_FULL = 0, UNIT_PREFETCH = 1, UNIT_RUN = 2 };  // MODE: whole unit / only fill the ring / run on a filled ring
 
 // `ub_base` (TAIL): value of the unit-barrier counter when the unit starts; every wave of the workgroup tracks it.
-template <int TN, int WK, int ACT, bool GROUP64, bool PERM, int MR, bool TAIL, int RING, int MODE>
+template <int TN, int WK, int ACT, bool GROUP64, bool PERM, int MR, bool TAIL, int RING, int MODE, bool NORMP = false>
 __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg, const int split, const int mslab,
                                                unsigned char* smem, const int ub_base, WeightRing<RING>& ring) {
     static_assert(MR == 1 || WK == 2, "64-row passes need the LDS of two k-parts");
     static_assert(!TAIL || (MR == 1 && !PERM && ACT != 1 && ACT != 3), "the decode tail runs 32-row, un-permuted units");
     static_assert(ACT != 3 || !PERM, "the rope epilogue is a decode form (<= 64 rows, no act-order)");
+    static_assert(!NORMP || (!TAIL && !PERM && GROUP64 && MR == 1 && (ACT == 2 || ACT == 3) && MODE == UNIT_FULL),
+                  "the norm phase exists in front of the 32-row gate_up and qkv units of the stand-alone kernel");
     static_assert(RING == 4 || RING == 8, "one or two chunks of weights in flight");
     static_assert(MODE == UNIT_FULL || GROUP64, "a pre-filled ring carries the scales of GROUP64 images");
     constexpr int NWAVES = TN * WK;
@@ -246,7 +253,7 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
         for (int j = 0; j < NJ; ++j) {
             f16x8 v, u;
 #ifndef TAIL_PLAIN_X
-            if (TAIL) {
+            if (TAIL || NORMP) {  // x was written by other workgroups of THIS launch: L1-bypassing loads
                 v = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, rowoff[j] + (uint32_t)kc * 2, 0, 16));
             } else
 #endif
@@ -329,6 +336,22 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
     if (wn == 0 && lane == 0) *sync_cnt = 0;
     // Issue order matters: a wave's loads return in order, so the (L2-resident) first x chunk goes out before the
     // HBM weight stream it would otherwise queue behind; then the small scale loads, then the ring of weights.
+    if (NORMP) {
+        // Phase 0: workgroup r normalises row r (all its threads), everybody meets at the grid barrier, and the weight ring
+        // of this unit — which does not depend on x — is requested between arriving and waiting, so that the first-data
+        // latency of the GEMM runs under the norm rows and the barrier instead of after them.
+        gsync::BarCtx bc = gsync::bar_init(a.bar);
+        const int blk = blockIdx.x;  // NORMP grids are one-dimensional (S == 1, one 32-row pass)
+        if (blk < a.norm.rows) gsync::norm_row<f16, 4>(a.norm, blk, reinterpret_cast<float*>(smem), NWAVES * 64);
+        gsync::grid_sync(a.bar, bc, [&]() {
+#pragma unroll
+            for (int s = 0; s < RING; ++s) szr[s] = sz_at(s);
+#pragma unroll
+            for (int s = 0; s < RING; ++s) wq[s] = w_at(s);
+        });
+        stage_load(0);
+        unit_barrier();
+    } else {
     stage_load(0);
 #ifndef TGIS_NO_XFIRST_BARRIER
     // Stand-alone kernel: the block-wide barrier that publishes the zeroed counters sits HERE, between the x requests and
@@ -352,6 +375,7 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
 #else
     unit_barrier();
 #endif
+    }
     auto group_sync = [&](int target) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add((lds_int*)sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

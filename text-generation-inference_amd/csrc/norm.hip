@@ -5,6 +5,7 @@
 //   y   = norm(res) * weight (+ bias)   [statistics in fp32 from the fp32 sum, one rounding at the end]
 // One 256-thread workgroup per row, 16-byte loads, row cached in registers (hidden <= 16384).
 #include "common.h"
+#include "grid_sync.h"
 
 namespace {
 
@@ -36,6 +37,25 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
     constexpr int MAXV = MAX_HIDDEN / (NT * 8);
     __shared__ float sh[NT / 64];
     const int64_t row = blockIdx.x;
+    if (RMS) {
+        // the RMS form is one function shared with the GEMM kernels that run the norm as their first phase
+        // (grid_sync.h): identical arithmetic by construction
+        gsync::NormPhase p;
+        p.slabs = PARTIAL ? slabs : nullptr;
+        p.S = S;
+        p.slab_ld = slab_ld;
+        p.xbias = xbias;
+        p.x = x;
+        p.residual = residual;
+        p.weight = weight;
+        p.y = y;
+        p.res_out = res_out;
+        p.rows = gridDim.x;
+        p.hidden = hidden;
+        p.eps = eps;
+        gsync::norm_row<T, MAXV, false>(p, (int)row, sh, NT);
+        return;
+    }
     const T* xr = PARTIAL ? nullptr : x + row * hidden;
     const T* rr = residual ? residual + row * hidden : nullptr;
     float v[MAXV][8];

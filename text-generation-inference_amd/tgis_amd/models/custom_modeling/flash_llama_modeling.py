@@ -85,6 +85,13 @@ DECODE_TAIL = os.getenv("TGIS_DECODE_TAIL", "false").lower() in ("1", "true")
 # 8.52 vs 7.78; tools/attn_fused_bench.py) — the prologue's dependent loads delay every block's first K/V load, and the
 # new token's scattered v stores collide with the same launch's reads of that page.
 FUSED_ROPE_ATTN = os.getenv("TGIS_FUSED_ROPE_ATTN", "false").lower() in ("1", "true")
+# TGIS_FUSED_NORM_GEMM=true: decode steps of up to 32 rows run each add + RMSNorm as the first phase of the int4 GEMM behind
+# it (input_layernorm inside the qkv + rope launch, post_attention_layernorm inside the gate_up launch): row r is normalised
+# by workgroup r, a grid barrier hands the rows over while the weight rings already stream; bit-identical results.  Off by
+# default: measured 1-1.5 us per layer SLOWER than the separate add + RMSNorm launches on every variant of what is
+# requested under the barrier (cfg3: 4.88 vs 4.84 ms/step on one box) — a grid barrier plus a cross-workgroup hand-off
+# costs what a launch boundary costs on this chip.  Needs the GPU to itself (refused under TGIS_ALLOW_SHARED_GPU).
+FUSED_NORM_GEMM = os.getenv("TGIS_FUSED_NORM_GEMM", "false").lower() in ("1", "true")
 
 
 class LlamaRMSNorm:
@@ -242,9 +249,46 @@ class FlashLlamaLayer:
         self.post_attention_layernorm = LlamaRMSNorm(prefix=f"{prefix}.post_attention_layernorm", weights=weights,
                                                      eps=config.rms_norm_eps)
 
+    def _norm_qkv(self, hidden_states, residual, cos, sin, position_ids, kv: KVArgs):
+        """input_layernorm + qkv + rotary + cache write as one launch, or None when this step / layer does not qualify."""
+        att = self.self_attn
+        lin = att.query_key_value.linear
+        w = getattr(lin, "rope_handle", None)
+        rows = hidden_states.shape[0]
+        if not (FUSED_NORM_GEMM and isinstance(w, native.GptqWeight) and kv.max_q_len == 1 and kv.slots is not None
+                and not kv.fresh_prefill and rows <= 32 and cos.shape[1] * 2 == att.head_size and not FUSED_ROPE_ATTN
+                and self.input_layernorm.weight.dtype == torch.float16
+                and native.rope_gemm_ok(rows, w, att.head_size) and native.gptq_norm_gemm_ok(rows, w, 3)):
+            return None
+        return native.gptq_norm_qkv_rope(hidden_states, residual, self.input_layernorm.weight,
+                                         self.input_layernorm.variance_epsilon, w, lin.bias, cos, sin, position_ids, kv.slots,
+                                         kv.cache.k_pool(self.layer_id), kv.cache.v_pool(self.layer_id), att.num_heads,
+                                         att.num_key_value_heads, att.head_size)
+
+    def _norm_gate_up(self, attn_output, res, kv: KVArgs):
+        """post_attention_layernorm + gate_up + SiLU * up as one launch, or None."""
+        lin = self.mlp.gate_up_proj.linear
+        w = getattr(lin, "q_handle", None)
+        rows = attn_output.shape[0]
+        if not (FUSED_NORM_GEMM and self.mlp.fused_epilogue and isinstance(w, native.GptqWeight) and kv.max_q_len == 1
+                and not kv.fresh_prefill and rows <= 32 and self.post_attention_layernorm.weight.dtype == torch.float16
+                and native.gptq_norm_gemm_ok(rows, w, 2)):
+            return None
+        return native.gptq_norm_gate_up(attn_output, res, self.post_attention_layernorm.weight,
+                                        self.post_attention_layernorm.variance_epsilon, w, lin.bias)
+
     def forward(self, hidden_states, residual, cos, sin, position_ids, cu_seqlens_q, kv: KVArgs):
-        normed_hidden_states, res = self.input_layernorm(hidden_states, residual)
-        attn_output = self.self_attn(normed_hidden_states, cos, sin, position_ids, cu_seqlens_q, self.layer_id, kv)
+        fused = self._norm_qkv(hidden_states, residual, cos, sin, position_ids, kv)
+        if fused is not None:
+            qkv, res = fused
+            attn_output = self.self_attn.o_proj(self.self_attn.attend(qkv, cu_seqlens_q, self.layer_id, kv), partial=True)
+        else:
+            normed_hidden_states, res = self.input_layernorm(hidden_states, residual)
+            attn_output = self.self_attn(normed_hidden_states, cos, sin, position_ids, cu_seqlens_q, self.layer_id, kv)
+        fused = self._norm_gate_up(attn_output, res, kv)
+        if fused is not None:
+            act, attn_res = fused
+            return self.mlp.down_proj(act, partial=True), attn_res
         normed_attn_res_output, attn_res = self.post_attention_layernorm(attn_output, res)
         mlp_output = self.mlp(normed_attn_res_output)
         return mlp_output, attn_res

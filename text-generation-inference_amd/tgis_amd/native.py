@@ -27,6 +27,13 @@ _vp = ctypes.c_void_p
 
 
 
+class NormIn(ctypes.Structure):
+    """tgis_norm_in of include/tgis_hip.h: the add + RMSNorm that runs as the first phase of a GEMM launch."""
+    _fields_ = [("slabs", ctypes.c_void_p), ("num_slabs", ctypes.c_int), ("slab_ld", ctypes.c_int64),
+                ("slab_bias", ctypes.c_void_p), ("x", ctypes.c_void_p), ("residual", ctypes.c_void_p),
+                ("weight", ctypes.c_void_p), ("eps", ctypes.c_float), ("y", ctypes.c_void_p), ("res_out", ctypes.c_void_p)]
+
+
 class TailLinear(ctypes.Structure):
     """tgis_tail_linear of include/tgis_hip.h."""
     _fields_ = [("prepared", _vp), ("bias", _vp), ("K", _c_i64), ("N", _c_i64), ("groups", _c_i64)]
@@ -68,6 +75,11 @@ SIGNATURES = {
     "tgis_dense_rope_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64]),
     "tgis_gptq_gemm_rope_f16": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _c_i64,
                                          _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp]),
+    "tgis_gptq_norm_gemm_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int]),
+    "tgis_gptq_norm_gemm_status": (_c_int, [_c_int]),
+    "tgis_gptq_norm_gate_up_f16": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp]),
+    "tgis_gptq_norm_qkv_rope_f16": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_i64,
+                                             _c_i64, _c_i64, _c_i64, _c_i64, _vp]),
     "tgis_gptq_lean_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int]),
     "tgis_gptq_lean_status": (_c_int, [_c_int]),
     "tgis_xsum_f16": (_c_int, [_vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64, _vp]),
@@ -374,6 +386,65 @@ def gptq_gemm_rope(x: torch.Tensor, w: GptqWeight, bias, cos, sin, positions, sl
                                                M, w.K, w.N, w.groups, H, Hkv, D, _stream()),
         "tgis_gptq_gemm_rope_f16")
     return out
+
+
+# ---- add + RMSNorm as the first phase of the int4 GEMM behind it ------------------------------------------------------
+def gptq_norm_gemm_ok(M: int, w: GptqWeight, act: int) -> bool:
+    """Whether the two-phase launch (norm rows -> grid barrier -> GEMM) serves M rows of this weight on this device; the
+    first call allocates the library's grid barrier, so make it outside any graph capture."""
+    cache = w.__dict__.setdefault("_norm_ok", {})
+    got = cache.get((M, act))
+    if got is None:
+        got = cache[(M, act)] = bool(
+            load_library().tgis_gptq_norm_gemm_ok(M, w.K, w.N, w.groups, int(w.perm is not None), act))
+    return got
+
+
+def gptq_norm_gemm_status(reset: bool = False) -> int:
+    return load_library().tgis_gptq_norm_gemm_status(int(reset))
+
+
+def _norm_in(x, residual, weight, eps: float):
+    """(NormIn, y, res) for x = tensor or Partial; res is x itself when there is nothing to add (as rmsnorm_residual)."""
+    n = NormIn()
+    if isinstance(x, Partial):
+        rows, hidden = x.shape
+        n.slabs, n.num_slabs, n.slab_ld, n.slab_bias, n.x = _ptr(x.slabs), x.S, x.ld, _ptr(x.bias), None
+        y = torch.empty((rows, hidden), dtype=x.dtype, device=x.device)
+        res = torch.empty_like(y)
+    else:
+        assert x.dim() == 2 and x.is_contiguous()
+        n.slabs, n.num_slabs, n.slab_ld, n.slab_bias, n.x = None, 0, 0, None, _ptr(x)
+        y = torch.empty_like(x)
+        res = torch.empty_like(x) if residual is not None else x
+    n.residual, n.weight, n.eps = _ptr(residual), _ptr(weight), float(eps)
+    n.y = _ptr(y)
+    n.res_out = _ptr(res) if (isinstance(x, Partial) or residual is not None) else None
+    return n, y, res
+
+
+def gptq_norm_gate_up(x, residual, norm_weight, eps: float, w: GptqWeight, bias=None):
+    """(silu(gate) * up [M, N/2], res) = post_attention_layernorm + gate_up_proj + activation in one launch."""
+    n, y, res = _norm_in(x, residual, norm_weight, eps)
+    M = y.shape[0]
+    out = torch.empty((M, w.N // 2), dtype=torch.float16, device=y.device)
+    _check(load_library().tgis_gptq_norm_gate_up_f16(ctypes.byref(n), _ptr(w.image), _ptr(bias), _ptr(out), out.stride(0), M,
+                                                     w.K, w.N, w.groups, _stream()), "tgis_gptq_norm_gate_up_f16")
+    return out, res
+
+
+def gptq_norm_qkv_rope(x, residual, norm_weight, eps: float, w: GptqWeight, bias, cos, sin, positions, slots, k_pool, v_pool,
+                       H: int, Hkv: int, D: int):
+    """(qkv [M, (H + 2 Hkv) D] with the rotated q in its first H D columns, res) = input_layernorm + query_key_value +
+    rotary embedding + cache write in one launch."""
+    n, y, res = _norm_in(x, residual, norm_weight, eps)
+    M = y.shape[0]
+    out = torch.empty((M, w.N), dtype=torch.float16, device=y.device)
+    _check(load_library().tgis_gptq_norm_qkv_rope_f16(ctypes.byref(n), _ptr(w.image), _ptr(bias), _ptr(positions), _ptr(slots),
+                                                      _ptr(cos), _ptr(sin), _ptr(out), out.stride(0), _ptr(k_pool),
+                                                      _ptr(v_pool), M, w.K, w.N, w.groups, H, Hkv, D, _stream()),
+           "tgis_gptq_norm_qkv_rope_f16")
+    return out, res
 
 
 # ---- lean decode GEMM: x travels with the row sums its producer computed ---------------------------------------------
