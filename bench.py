@@ -131,6 +131,17 @@ def cpu_baseline(cfg, quantize, B, ctx, groupsize=128):
                       f"x{cfg.num_hidden_layers} layers + lm_head/greedy"}
 
 
+def fused_rope_launches_per_step(lm):
+    """Layers whose qkv projection runs the rotary embedding + cache write in its GEMM epilogue at this batch size."""
+    n = 0
+    for layer in getattr(lm.model.model, "layers", []):
+        att = getattr(layer, "self_attn", None)
+        lin = getattr(getattr(att, "query_key_value", None), "linear", None)
+        if getattr(lin, "rope_handle", None) is not None:
+            n += 1
+    return n
+
+
 def pmc_traffic(config, B, ctx_mean):
     """HBM bytes per attention launch from the committed rocprofv3 counter passes (tools/profile_round.sh: FETCH_SIZE
     and WRITE_SIZE in separate --pmc runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
@@ -400,7 +411,10 @@ def main():
                                  "frac": round(g_bytes / g_avg_s / 1e9 / HBM_PEAK_GBS, 4),
                                  "traffic": pmc_gemm_traffic(args.config, B, ctx_mean),
                                  "launches": int(n_gemm), "avg_launch_us": round(g_avg_s * 1e6, 2),
-                                 "algorithmic_bytes_per_launch": int(g_bytes)}
+                                 "algorithmic_bytes_per_launch": int(g_bytes),
+                                 # one GEMM launch per layer may carry the rotary embedding + cache write in its epilogue
+                                 # (round 3: the former rope_kv_write launch is inside this average now)
+                                 "launches_with_rope_epilogue_per_step": fused_rope_launches_per_step(lm)}
 
     toks_per_s = B * K / elapsed
     ab = algorithmic_bytes_per_step(cfg, quantize, B, ctx_timed_mean, tp)

@@ -176,7 +176,15 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
     TRACE(0);
     TRACE_RT(14);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Stand-alone kernel: k-part = w % WK, so that every k-part owns waves of every age.  A CU serves its older waves first
+    // (issue and memory return): with k-part = w / TN the k-part of the youngest waves finished 2.5 us (gate_up) after the
+    // k-part of the oldest ones, and everybody waited for it; the per-chunk sync of a mixed k-part holds its old waves back
+    // instead, which is what lets the young ones catch up.
+#ifdef TGIS_KPART_BY_AGE
     const int wn = w % TN, wk = w / TN, ltid = wn * 64 + lane;
+#else
+    const int wn = TAIL ? w % TN : w / WK, wk = TAIL ? w / TN : w % WK, ltid = wn * 64 + lane;
+#endif
     f16* xs = reinterpret_cast<f16*>(smem) + wk * (2 * XR * RS);  // this k-part's [2][XR][RS]
     const int m0 = mslab * XR;
     const int mrows = min(XR, a.M - m0);

@@ -92,11 +92,25 @@ for a_, b_ in pairs:
 # chip-wide picture from s_memrealtime (100 MHz): when do waves enter, when do reducer waves reach the epilogue
 rt0, rt1 = t[:, :, 14], t[:, :, 15]
 m0, m1 = rt0 != 0, rt1 != 0
-if not (m0.any() and m1.any()):
-    sys.exit(0)
-base = rt0[m0].min().item()
-e = (rt0[m0] - base).float() * 10.0
-x = (rt1[m1] - base).float() * 10.0
-qs = torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0])
-print("  realtime ns since first wave entry:  entry  ", [int(v) for v in torch.quantile(e, qs)])
-print("                                       epilogue", [int(v) for v in torch.quantile(x, qs)])
+if m0.any() and m1.any():
+    base = rt0[m0].min().item()
+    e = (rt0[m0] - base).float() * 10.0
+    x = (rt1[m1] - base).float() * 10.0
+    qs = torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0])
+    print("  realtime ns since first wave entry:  entry  ", [int(v) for v in torch.quantile(e, qs)])
+    print("                                       epilogue", [int(v) for v in torch.quantile(x, qs)])
+
+# per-wave picture: when does each wave of a block finish its last chunk, relative to the block's earliest entry
+t9 = t[:, :, 9].double()
+t0b = t[:, :, 0].double()
+valid = (t[:, :, 9] != 0) & (t[:, :, 0] != 0)
+if valid.any():
+    nw = int(valid.any(dim=0).sum())
+    rows_ = valid.any(dim=1)
+    base_b = torch.where(valid, t0b, torch.full_like(t0b, float("inf"))).min(dim=1).values
+    rel = (t9 - base_b[:, None])
+    ent = (t0b - base_b[:, None])
+    print("  per wave (index = wk * TN + wn): median cycles from the block's first entry to [entry | last chunk done]")
+    for w_ in range(nw):
+        m_ = valid[:, w_] & rows_
+        print(f"    wave {w_:2d}: entry {ent[m_, w_].median():7.0f}   last chunk done {rel[m_, w_].median():8.0f}   p90 {torch.quantile(rel[m_, w_], 0.9):8.0f}")
