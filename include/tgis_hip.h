@@ -124,7 +124,7 @@ int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void* prepared,
  * head a 32-column tile holds 16 dims and their 16 rotation partners, so every wave owns complete rotation pairs.
  * Full rotary span only (rot_dim == D).  tgis_gptq_rope_ok: whether the launch exists for the shape (1 <= M <= 64, groups
  * of 64 * 2^n rows, no act-order, D % 32 == 0) AND is expected to beat the two launches it replaces (its unsplit plan
- * still covers the chip, or the matrix is launch-bound anyway); the entry point itself only checks the former. */
+ * still covers the chip: >= 128 workgroups); the entry point itself only checks the former. */
 #define TGIS_GPTQ_ROPE_IMAGE(D, rotated_heads) (2 | ((int)(D) << 8) | ((int)(rotated_heads) << 20))
 int tgis_gptq_rope_ok(int64_t M, int64_t K, int64_t N, int64_t groups, int act_order, int64_t D);
 int tgis_gptq_gemm_rope_f16(const void* x, int64_t ldx, const void* prepared, const void* bias, const int32_t* positions,

@@ -242,10 +242,10 @@ extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared,
 // ---- qkv projection with the rotary embedding and the cache write in its epilogue (dense weights) ---------------------
 extern "C" int tgis_dense_rope_ok(int64_t M, int64_t K, int64_t N, int64_t D) {
     if (M < 1 || M > 64 || D < 32 || D % 32 || N <= 0 || N % D || K <= 0 || K % 8) return 0;
-    // as tgis_gptq_rope_ok: the unsplit plan must still cover the chip, or the matrix be launch-bound anyway
+    // as tgis_gptq_rope_ok: the unsplit plan must still cover the chip
     const DensePlan pl = plan_dense(K, N, M, 2);
     const int64_t blocks = cdiv64(cdiv64(N, 32), pl.TN);
-    return (blocks >= 128 || K * N * 2 <= (12 << 20)) ? 1 : 0;
+    return blocks >= 128 ? 1 : 0;
 }
 
 extern "C" int tgis_dense_gemm_rope(const void* x, int64_t ldx, const void* prepared, const void* bias,

@@ -766,12 +766,12 @@ extern "C" int tgis_gptq_rope_ok(int64_t M, int64_t K, int64_t N, int64_t groups
     if (M < 1 || M > 64 || act_order || groups <= 0 || K % groups || D < 32 || D % 32 || N <= 0 || N % D) return 0;
     const int64_t gs = K / groups, spg = gs / 64;
     if (!(groups == 1 || (gs % 64 == 0 && (spg & (spg - 1)) == 0))) return 0;
-    // The epilogue needs the whole k range in one block (no split-K): worth it while that plan still covers the chip, or
-    // when the matrix is so small that the launch it saves outweighs the narrower grid (measured: 7B qkv at 32 rows 192
-    // blocks -17 %; 70B qkv at 64 rows, 80 blocks of 42 MB, +5 % -> excluded).
+    // The epilogue needs the whole k range in one block (no split-K): worth it only while that plan still covers the chip
+    // (measured: 7B qkv at 32 rows, 192 blocks: 14.9 vs 17.2 us for the pair; 70B qkv at 64 rows, 80 blocks of 42 MB: +5 % on
+    // the step; a TP = 8 shard of the 7B qkv, 24 blocks: +2 % on the rank-step; TinyLlama dense, 40 blocks: +-0).
     const GemmPlan pl = plan_gemm(K, N, 2, M);
     const int64_t blocks = cdiv64(cdiv64(N, 32), pl.TN);
-    return (blocks >= 128 || K * N / 2 <= (12 << 20)) ? 1 : 0;
+    return blocks >= 128 ? 1 : 0;
 }
 
 extern "C" int tgis_gptq_gemm_rope_f16(const void* x, int64_t ldx, const void* prepared, const void* bias,
