@@ -17,6 +17,8 @@ _main = __name__ == "__main__"
 M = int(sys.argv[1]) if _main and len(sys.argv) > 1 else 32
 MODE = sys.argv[2] if _main and len(sys.argv) > 2 else "both"
 SHAPES = [("qkv", 4096, 12288, 0), ("o", 4096, 4096, 0), ("gate_up", 4096, 22016, 2), ("down", 11008, 4096, 0)]
+if os.environ.get("LEAN_SHAPES") == "70b":  # Llama-2-70B (whole matrices, one GPU)
+    SHAPES = [("qkv", 8192, 10240, 0), ("o", 8192, 8192, 0), ("gate_up", 8192, 57344, 2), ("down", 28672, 8192, 0)]
 
 
 def make(K, N, gs, seed, gate_up=False):
@@ -78,7 +80,7 @@ def check():
 
 def bench():
     for name, K, N, act in SHAPES:
-        sets = 6
+        sets = 6 if K * N < (1 << 27) else 3
         hs = []
         for i in range(sets):
             G = K // 128
