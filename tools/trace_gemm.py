@@ -25,7 +25,7 @@ if len(sys.argv) > 4 and sys.argv[4] != "-":
     os.environ["TGIS_GPTQ_PLAN"] = sys.argv[4]
 LEAN = len(sys.argv) > 5 and sys.argv[5] == "lean"  # the lean kernel (TGIS_LEAN_RING / TGIS_LEAN_LD select its form)
 dev = torch.device("cuda:0")
-gs, M = 128, 32
+gs, M = 128, int(os.environ.get("TRACE_M", "32"))
 G = K // gs
 sets = []
 for i in range(4):
@@ -59,7 +59,7 @@ e0.record()
 run(3)
 e1.record()
 torch.cuda.synchronize()
-print(f"K={K} N={N} act={act}: event time {e0.elapsed_time(e1) * 1e3:.1f} us")
+print(f"M={M} K={K} N={N} act={act}: event time {e0.elapsed_time(e1) * 1e3:.1f} us")
 t = trace.view(NB, 16, 32).cpu()
 used = t[:, :, 0] != 0
 t0 = t[:, :, 0][used].min().item()
