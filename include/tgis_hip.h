@@ -212,7 +212,10 @@ int64_t tgis_dense_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
  * act 0: plain.  act 1: x is [M, 2K] (gate | up) and the operand is silu(gate) * up, formed while it is staged
  * (down_proj after an un-fused gate_up).  act 2: the image has flags bit 0 and out is [M, N/2] =
  * silu(x @ Wgate^T) * (x @ Wup^T), each factor rounded to the model dtype as the reference's eager ops do
- * (flash_llama_modeling.py:332-335); the down projection then runs with act 0. */
+ * (flash_llama_modeling.py:332-335); the down projection then runs with act 0.
+ * act 4 / 5: out = gelu(T(x @ W^T + bias)) in the model dtype, exact erf form / tanh approximation — the `self.act(...)`
+ * behind `c_fc` (flash_santacoder_modeling.py:284-306) applied to the rounded output where it is finished (the epilogue of an
+ * unsplit plan, the split-K reduce otherwise): bit-identical to tgis_dense_gemm(act 0) followed by tgis_gelu. */
 int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared, const void* bias, void* out,
                     int64_t ldo, int64_t M, int64_t K, int64_t N, int dtype, int out_f32, int act,
                     void* workspace, int64_t workspace_bytes, void* stream);

@@ -68,6 +68,8 @@ def _dense_gemm(x, w, ws, bias=None, out_f32=False, act=0, out=None):
         y = y + bias.float()
     if act == 2:
         return ops_ref.silu_mul(y.to(w.dtype), w.N // 2).to(w.dtype)
+    if act in (4, 5):
+        return ops_ref.gelu(y.to(w.dtype), act == 5).to(w.dtype)
     return y if out_f32 else y.to(w.dtype)
 
 

@@ -608,6 +608,26 @@ def test_dense_gemm_rope_equals_gemm_then_rope_kv_write(nat, gpu_device, dtype, 
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tanh", [False, True])
+@pytest.mark.parametrize("M,K,N", [(32, 1024, 24576), (7, 512, 16384 + 40), (32, 4096, 256), (64, 2048, 6144), (1, 256, 72)])
+def test_dense_gemm_gelu_equals_gemm_then_gelu(nat, gpu_device, dtype, tanh, M, K, N):
+    """tgis_dense_gemm act 4 / 5 (GELU of the rounded sum + bias, in the epilogue of an unsplit plan or in the split-K
+    reduce) against tgis_dense_gemm + tgis_gelu, bit for bit, and against the oracle's GELU of the fp32 product."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = (torch.randn(M, K, generator=g) * 0.7).to(dtype).to(gpu_device)
+    wt = (torch.randn(N, K, generator=g) * 0.04).to(dtype).to(gpu_device)
+    bv = (torch.randn(N, generator=g) * 0.2).to(dtype).to(gpu_device)
+    w = nat.DenseWeight(wt)
+    ws = nat.Workspace(w.workspace_bytes(M), gpu_device)
+    two = nat.gelu(nat.dense_gemm(x, w, ws, bias=bv), tanh)
+    one = nat.dense_gemm(x, w, ws, bias=bv, act=5 if tanh else 4)
+    assert torch.equal(one, two), "GELU in the GEMM differs from GEMM + tgis_gelu"
+    lin = (x.float().cpu() @ wt.float().cpu().t() + bv.float().cpu()).to(dtype)
+    eps = 2.0 ** -11 if dtype == torch.float16 else 2.0 ** -8
+    _close(one, ops_ref.gelu(lin, tanh), rtol=4 * eps, atol=8 * eps * float(lin.abs().max()), what="gelu(x W^T + b) vs oracle")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,K,I", [(16, 2048, 5632), (32, 4096, 11008), (3, 256, 48), (40, 512, 1376), (64, 2048, 5632)])
 def test_dense_gemm_gate_up_epilogue(nat, gpu_device, dtype, M, K, I):
     """Dense act=2: [gate | up] projection with SiLU(gate)*up in the epilogue (pairs interleaved at prepare time) against

@@ -128,3 +128,14 @@ __device__ __forceinline__ void sum_slabs8(const float* sp, int64_t stride, int 
 }
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// GELU on an fp32 value (exact erf form, or the tanh approximation): ONE function for tgis_gelu and for the GEMM epilogues
+// that apply it to their rounded output.  Not inlined: inside a caller the compiler contracts the expression (and the
+// library's erf / tanh polynomials) with whatever surrounds it, and the two forms then differ in the last bit.
+__device__ __attribute__((noinline)) inline float gelu_f32(float f, bool tanh_approx) {
+    if (tanh_approx) {
+        float inner = 0.7978845608028654f * (f + 0.044715f * f * f * f);
+        return 0.5f * f * (1.f + tanhf(inner));
+    }
+    return 0.5f * f * (1.f + erff(f * 0.7071067811865476f));
+}

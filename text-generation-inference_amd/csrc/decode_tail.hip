@@ -557,6 +557,7 @@ int fill_dense(DenseArgs& a, int& tw, int& gx, int& gy, const tgis_tail_linear& 
     a.out_f32 = 0;
     a.slabs = slabs;
     a.partial = direct ? 0 : 1;
+    a.gelu = 0;
     a.err = nullptr;
     tw = pl.TN * 10 + pl.WK;
     gx = (int)cdiv64(a.NT, pl.TN);

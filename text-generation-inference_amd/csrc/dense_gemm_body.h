@@ -33,6 +33,7 @@ struct DenseArgs {
     int out_f32;
     float* slabs;  // [Mslabs][S][32][NT*32] f32 partial sums (S > 1 or partial mode)
     int partial;   // 1: always leave fp32 slabs (deferred reduce), never write `out`
+    int gelu;      // model-dtype output only: 0 none, 1 GELU (erf), 2 GELU (tanh) applied to the rounded sum + bias
     unsigned* err; // decode tail: word that receives a code when a bounded spin gives up (nullptr otherwise)
     // ACT == 3 (rope image, tgis_dense_prepare flags bit 1): the epilogue rotates q / k heads and writes k / v into their
     // cache pages; `out` is the q tensor (see tgis_dense_gemm_rope)
@@ -55,6 +56,14 @@ template <typename T>
 struct DenseRing {
     typename VecT<T>::x8 wq[DRING][4];
 };
+
+// sum + bias -> model dtype; with `gelu` the activation of the ROUNDED value (what tgis_gelu would read back), rounded again
+template <typename T>
+__device__ __forceinline__ T finish_out(float v, int gelu) {
+    T t = from_f32<T>(v);
+    if (gelu) t = from_f32<T>(gelu_f32(to_f32(t), gelu == 2));
+    return t;
+}
 
 // Same structure as gptq_gemm_unit without the dequantisation: a unit of TN*WK waves owns 32*TN columns x KR rows; wave
 // (tile wn, k-part wk) streams its tile's fragments over its own k-range (4 KiB per k64-step, two steps in flight,
@@ -397,7 +406,7 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
                     if (a.out_f32)
                         reinterpret_cast<float*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = fin[mr][j] + bv;
                     else
-                        reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = from_f32<T>(fin[mr][j] + bv);
+                        reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = finish_out<T>(fin[mr][j] + bv, a.gelu);
                 }
         } else {
 #pragma unroll
@@ -546,7 +555,7 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
                 if (a.out_f32)
                     reinterpret_cast<float*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = acc[mr][r] + bv;
                 else
-                    reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = from_f32<T>(acc[mr][r] + bv);
+                    reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = finish_out<T>(acc[mr][r] + bv, a.gelu);
             }
     } else {
 #pragma unroll
@@ -657,6 +666,7 @@ static inline DensePlan plan_dense(int64_t K, int64_t N, int64_t M = 32, int act
     }
     int64_t KRc = cdiv64(kchunks, S);
     if (KRc < WK) WK = 2;
+    if (TN == 3 && WK == 2) TN = 4;  // short K under a wide N: (3, 2) is not instantiated
     KRc = cdiv64(KRc, WK) * WK;
     while (S > 1 && (S - 1) * KRc >= kchunks) --S;
     return {(int)(KRc * DKC), (int)S, WK, TN, MR};

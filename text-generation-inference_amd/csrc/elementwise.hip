@@ -33,15 +33,7 @@ __global__ void gelu_kernel(const T* __restrict__ x, T* __restrict__ out, int64_
     V8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        float f = to_f32(v[e]);
-        float r;
-        if (tanh_approx) {
-            float inner = 0.7978845608028654f * (f + 0.044715f * f * f * f);
-            r = 0.5f * f * (1.f + tanhf(inner));
-        } else {
-            r = 0.5f * f * (1.f + erff(f * 0.7071067811865476f));
-        }
-        o[e] = from_f32<T>(r);
+        o[e] = from_f32<T>(gelu_f32(to_f32(v[e]), tanh_approx != 0));
     }
     st16(out + idx * 8, o);
 }

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(64 * TN * WK) void dense_gemm_kernel(DenseArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float* __restrict__ slabs,
                                                                   const T* __restrict__ bias, void* __restrict__ out,
-                                                                  int64_t ldo, int M, int N, int NP, int S, int out_f32) {
+                                                                  int64_t ldo, int M, int N, int NP, int S, int out_f32,
+                                                                  int gelu) {
     const int np4 = NP >> 2;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int mslab = blockIdx.y;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float* _
         if (out_f32)
             reinterpret_cast<float*>(out)[o] = f;
         else
-            reinterpret_cast<T*>(out)[o] = from_f32<T>(f);
+            reinterpret_cast<T*>(out)[o] = dense::finish_out<T>(f, gelu);
     }
 }
 
@@ -138,7 +139,7 @@ static int launch_dense(const DenseArgs& a, const DensePlan& pl, int act, int64_
         const int NP = a.NT * 32;
         dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 4), 256), (unsigned)mslabs32);
         hipLaunchKernelGGL(dense_splitk_reduce_kernel<T>, rgrid, dim3(256), 0, st, a.slabs, (const T*)a.bias, a.out, a.ldo,
-                           a.M, a.N, NP, a.S, a.out_f32);
+                           a.M, a.N, NP, a.S, a.out_f32, a.gelu);
         TGIS_CHECK_LAUNCH();
     }
     return TGIS_OK;
@@ -187,7 +188,7 @@ static int dense_check(const void* x, int64_t ldx, const void* prepared, int64_t
     TGIS_CHECK_ARG(M >= 0 && K > 0 && N > 0, "tgis_dense_gemm: bad shape");
     TGIS_CHECK_ARG(K % 8 == 0, "tgis_dense_gemm: K (%ld) must be a multiple of 8", (long)K);
     TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "tgis_dense_gemm: bad dtype");
-    TGIS_CHECK_ARG(act >= 0 && act <= 2, "tgis_dense_gemm: act must be 0, 1 or 2");
+    TGIS_CHECK_ARG((act >= 0 && act <= 2) || act == 4 || act == 5, "tgis_dense_gemm: act must be 0, 1, 2, 4 or 5");
     TGIS_CHECK_ARG(act != 2 || N % 32 == 0, "tgis_dense_gemm: act 2 needs a gate|up image (N / 2 a multiple of 16)");
     TGIS_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, "tgis_dense_gemm: x rows must be 16-byte aligned");
     return TGIS_OK;
@@ -212,6 +213,7 @@ static void dense_fill(DenseArgs& a, const void* x, int64_t ldx, const void* pre
     a.out_f32 = out_f32;
     a.slabs = slabs;
     a.partial = partial;
+    a.gelu = 0;
     a.err = nullptr;
     a.positions = a.slots = nullptr;
     a.cosb = a.sinb = nullptr;
@@ -227,14 +229,18 @@ extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared,
     TGIS_CHECK_ARG(out, "tgis_dense_gemm: null out");
     if (M == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
+    const int gelu = act == 4 ? 1 : act == 5 ? 2 : 0;  // GELU of the finished sum: epilogue (unsplit) or split-K reduce
+    if (gelu) act = 0;
     DensePlan pl = plan_dense(K, N, M, act);
     TGIS_CHECK_ARG(act != 2 || (!out_f32 && pl.S == 1), "tgis_dense_gemm: act 2 writes the model dtype, unsplit");
+    TGIS_CHECK_ARG(!gelu || !out_f32, "tgis_dense_gemm: act 4 / 5 (GELU) write the model dtype");
     const int64_t need = tgis_dense_gemm_workspace_bytes(M, K, N);
     TGIS_CHECK_ARG(workspace && workspace_bytes >= need, "tgis_dense_gemm: workspace too small (%ld < %ld)",
                    (long)workspace_bytes, (long)need);
     TgisTimedScope timed(TGIS_OP_DENSE_GEMM, st);
     DenseArgs a;
     dense_fill(a, x, ldx, prepared, bias, out, ldo, M, K, N, out_f32, (float*)((uint8_t*)workspace + 4096), 0, pl);
+    a.gelu = gelu;
     return dtype == TGIS_F16 ? launch_dense<f16>(a, pl, act, cdiv64(M, 32), st)
                              : launch_dense<bf16>(a, pl, act, cdiv64(M, 32), st);
 }
@@ -286,7 +292,7 @@ extern "C" int tgis_dense_gemm_partial(const void* x, int64_t ldx, const void* p
                                        int* num_slabs, int64_t* slab_ld, void* stream) {
     int rc = dense_check(x, ldx, prepared, M, K, N, dtype, act);
     if (rc != TGIS_OK) return rc;
-    TGIS_CHECK_ARG(act != 2, "tgis_dense_gemm_partial: the SiLU * up epilogue needs the finished sum (use tgis_dense_gemm)");
+    TGIS_CHECK_ARG(act == 0 || act == 1, "tgis_dense_gemm_partial: the SiLU * up and GELU epilogues need the finished sum (use tgis_dense_gemm)");
     TGIS_CHECK_ARG(M >= 1 && cdiv64(M, 32) <= 65535, "tgis_dense_gemm_partial: bad M");
     TGIS_CHECK_ARG(slabs && slabs_bytes >= tgis_dense_gemm_partial_bytes(M, K, N),
                    "tgis_dense_gemm_partial: slab buffer too small");

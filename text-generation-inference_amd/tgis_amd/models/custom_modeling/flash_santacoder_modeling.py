@@ -17,6 +17,7 @@ from tgis_amd import native
 from tgis_amd.utils.graph_segments import collective
 from tgis_amd.models.custom_modeling.flash_llama_modeling import KVArgs
 from tgis_amd.utils.layers import (
+    FastLinear,
     TensorParallelColumnLinear,
     TensorParallelEmbedding,
     TensorParallelHead,
@@ -172,8 +173,11 @@ class MLP:
         self.c_proj = load_row(config, prefix=f"{prefix}.c_proj", weights=weights, bias=True)
 
     def forward(self, hidden_states):
-        h = self.c_fc(hidden_states)
-        return self.c_proj(native.gelu(h, self.tanh), partial=True)  # summed by the next block's add + LayerNorm
+        if isinstance(self.c_fc.linear, FastLinear):
+            h = self.c_fc(hidden_states, gelu=self.tanh)  # GELU where the decode GEMM finishes its output
+        else:
+            h = native.gelu(self.c_fc(hidden_states), self.tanh)
+        return self.c_proj(h, partial=True)  # summed by the next block's add + LayerNorm
 
     __call__ = forward
 

@@ -27,6 +27,8 @@ DEFER_REDUCE = os.getenv("TGIS_DEFER_REDUCE", "true").lower() not in ("0", "fals
 # decode batches of up to 32 rows: rotary embedding + cache write in the epilogue of the int4 qkv GEMM (one launch
 # instead of GEMM + tgis_rope_kv_write, no split-K slabs).  Costs a second image of the qkv weights.
 FUSED_ROPE_GEMM = os.getenv("TGIS_FUSED_ROPE_GEMM", "true").lower() not in ("0", "false")
+# GELU applied by the dense decode GEMM that produces its operand (TGIS_FUSED_GELU_GEMM=false: a launch of its own)
+FUSED_GELU_GEMM = os.getenv("TGIS_FUSED_GELU_GEMM", "true").lower() not in ("0", "false")
 
 _WORKSPACES = {}
 
@@ -74,7 +76,16 @@ class FastLinear:
             H, Hkv, D = heads
             self.rope_handle = native.DenseWeight(self.weight, rope=(D, H + Hkv))
 
-    def forward(self, x: torch.Tensor, act: int = 0, out_f32: bool = False, partial: bool = False) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, act: int = 0, out_f32: bool = False, partial: bool = False,
+                gelu: Optional[bool] = None) -> torch.Tensor:
+        """`gelu` (None / False: exact erf form / True: tanh approximation): the activation behind this projection
+        (santacoder's `c_fc`, flash_santacoder_modeling.py:303-305) — applied where the decode GEMM finishes its output
+        instead of by a launch of its own; same bits as the two steps."""
+        if gelu is not None:
+            assert act == 0 and not out_f32 and not partial and not self._gate_up
+            if x.shape[0] <= SKINNY_MAX_M and FUSED_GELU_GEMM:
+                return native.dense_gemm(x, self.prepared, workspace(x.device), bias=self.bias, act=5 if gelu else 4)
+            return native.gelu(self.forward(x), gelu)
         if self._gate_up:
             # output is the activated [M, I] tensor
             if x.shape[0] <= SKINNY_MAX_M:
