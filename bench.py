@@ -365,6 +365,19 @@ def main():
         last = next(iter(lm._graphs.values()), None)
         logits_finite = bool(torch.isfinite(last.logits).all()) if last is not None and last.logits is not None else None
 
+        # the captured step replayed back to back (same inputs again; nothing reads this batch afterwards): GPU time of a
+        # step without the host's per-step work (three small copies in, token bookkeeping, one copy out)
+        graph_ms = None
+        if tp == 1 and last is not None and isinstance(getattr(last, "graph", None), torch.cuda.CUDAGraph):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            last.graph.replay()
+            e0.record()
+            for _ in range(10):
+                last.graph.replay()
+            e1.record()
+            sync()
+            graph_ms = e0.elapsed_time(e1) / 10.0
+
         roofline = roofline_gemm = None
         if not args.no_roofline:  # every rank runs it (the forward contains collectives when tp > 1)
             # Instrumented pass over the same workload: eager launches (HIP events cannot bracket nodes of a
@@ -425,6 +438,7 @@ def main():
                    else f"decode tokens/sec ({args.config}, batch {B}, ctx {ctx_mean}) + p50 step latency"),
         "value": round(toks_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "p50_step_ms": round(sorted(step_ms)[len(step_ms) // 2], 4),
+        "graph_ms_per_step": None if graph_ms is None else round(graph_ms, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16",
         "data": "synthetic (seeded weights at the real shapes; KV from a real prefill of seeded token ids)",
         "config": {"workload": f"{args.config} decode, B={B}, mean ctx {ctx_timed_mean:.1f} "

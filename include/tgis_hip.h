@@ -325,6 +325,15 @@ int tgis_embedding(const int64_t* ids, const void* table, const int32_t* positio
  * positions[b] (int32) -> slots[b] = block_tables[b][pos/32]*32 + pos%32 ; ctx_lens[b] = pos+1. */
 int tgis_decode_slots(const int32_t* positions, const int32_t* block_tables, int64_t max_pages,
                       int32_t* slots, int32_t* ctx_lens, int64_t B, void* stream);
+/* What follows a decode step on the device, in one launch (flash_causal_lm.py:457 `cu_seqlens.add_(cu_seqlens_q)`, :499
+ * `position_ids += 1`, :533-535 `all_input_ids_tensor.scatter_(1, position_ids, next ids)`): position_ids int64 [B] += 1;
+ * all_input_ids[b][position_ids[b]] = ids[b] (row stride ld_all, NULL: skip); ids_copy [B] = ids (NULL: skip; the caller's
+ * next `input_ids`, since `ids` is a buffer the next step overwrites); cu_seqlens int32 [B + 1] += cu_seqlens_q (NULL:
+ * skip); stage_ids int64 [B] / stage_positions int32 [B]: the same new ids / positions once more, e.g. into the static
+ * input buffers of a captured decode step (NULL: skip). */
+int tgis_decode_advance(const int64_t* ids, int64_t* ids_copy, int64_t* position_ids, int64_t* all_input_ids,
+                        int64_t ld_all, int32_t* cu_seqlens, const int32_t* cu_seqlens_q, int64_t* stage_ids,
+                        int32_t* stage_positions, int64_t B, void* stream);
 
 /* ---- greedy sampling (Greedy + log_softmax + gather, utils/tokens.py:44-46,238-271,388-397) ------ */
 /* Per row: token = argmax (lowest id on ties), logprob = logit[token] - logsumexp(row).

@@ -607,6 +607,31 @@ def test_dense_gemm_rope_equals_gemm_then_rope_kv_write(nat, gpu_device, dtype, 
         _close(Vp[s_ & 31], qkv_ref[b, (H + Hkv) * D:].view(Hkv, D), rtol=2 * eps, atol=6 * eps * scale, what="fused v page")
 
 
+@pytest.mark.parametrize("B", [1, 7, 64, 200])
+def test_decode_advance_equals_the_reference_ops(nat, gpu_device, B):
+    """tgis_decode_advance against the reference's statements after a decode step (flash_causal_lm.py:457,499,533-535)."""
+    g = torch.Generator().manual_seed(B)
+    L = 50
+    ids = torch.randint(0, 32000, (B,), generator=g).to(gpu_device)
+    pos = torch.randint(0, L - 1, (B,), generator=g).to(gpu_device)
+    all_ids = torch.randint(0, 32000, (B + 3, L), generator=g).to(gpu_device)[:B]  # a view with more rows behind it
+    cu_q = torch.arange(B + 1, dtype=torch.int32, device=gpu_device)
+    cu = (torch.cumsum(torch.randint(1, 40, (B + 1,), generator=g), 0).int() - 1).to(gpu_device)
+    want_pos = pos + 1
+    want_all = all_ids.clone().scatter_(1, want_pos[:, None], ids[:, None])
+    want_cu = cu + cu_q
+    st_ids = torch.zeros(B, dtype=torch.int64, device=gpu_device)
+    st_pos = torch.zeros(B, dtype=torch.int32, device=gpu_device)
+    out = nat.decode_advance(ids, pos, all_ids, cu, cu_q, stage_ids=st_ids, stage_positions=st_pos)
+    assert out.data_ptr() != ids.data_ptr() and torch.equal(out, ids)
+    assert torch.equal(pos, want_pos) and torch.equal(all_ids, want_all) and torch.equal(cu, want_cu)
+    assert torch.equal(st_ids, ids) and torch.equal(st_pos, want_pos.int())
+    # optional outputs left out: only the positions move
+    pos2 = pos.clone()
+    out2 = nat.decode_advance(ids, pos2)
+    assert torch.equal(out2, ids) and torch.equal(pos2, want_pos + 1)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("tanh", [False, True])
 @pytest.mark.parametrize("M,K,N", [(32, 1024, 24576), (7, 512, 16384 + 40), (32, 4096, 256), (64, 2048, 6144), (1, 256, 72)])

@@ -72,6 +72,27 @@ __global__ void decode_slots_kernel(const int32_t* __restrict__ positions, const
     ctx[b] = pos + 1;
 }
 
+// The device side of what follows a decode step (reference flash_causal_lm.py:457,499,533-535), one launch:
+// position_ids += 1; all_input_ids[b][position] = new id; a private copy of the ids (the chooser's / graph's buffer is
+// reused by the next step); cu_seqlens += cu_seqlens_q; optionally the next step's inputs straight into a decode graph's
+// static buffers.
+__global__ void decode_advance_kernel(const int64_t* __restrict__ ids, int64_t* __restrict__ ids_copy,
+                                      int64_t* __restrict__ position_ids, int64_t* __restrict__ all_ids, int64_t ld_all,
+                                      int32_t* __restrict__ cu_seqlens, const int32_t* __restrict__ cu_q,
+                                      int64_t* __restrict__ stage_ids, int32_t* __restrict__ stage_pos, int64_t B) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > B) return;
+    if (cu_seqlens) cu_seqlens[b] += cu_q[b];  // B + 1 entries
+    if (b == B) return;
+    const int64_t id = ids[b];
+    const int64_t pos = position_ids[b] + 1;
+    position_ids[b] = pos;
+    if (all_ids && pos >= 0 && pos < ld_all) all_ids[b * ld_all + pos] = id;
+    if (ids_copy) ids_copy[b] = id;
+    if (stage_ids) stage_ids[b] = id;
+    if (stage_pos) stage_pos[b] = (int32_t)pos;
+}
+
 // argmax (lowest index on ties) + logsumexp per row; one 1024-thread block per row.
 template <typename T>
 __global__ __launch_bounds__(1024) void argmax_logprob_kernel(const T* __restrict__ logits, int64_t ld,
@@ -188,6 +209,18 @@ extern "C" int tgis_decode_slots(const int32_t* positions, const int32_t* block_
     if (B == 0) return TGIS_OK;
     hipLaunchKernelGGL(decode_slots_kernel, dim3((unsigned)cdiv64(B, 64)), dim3(64), 0, (hipStream_t)stream,
                        positions, block_tables, max_pages, slots, ctx_lens, B);
+    TGIS_CHECK_LAUNCH();
+    return TGIS_OK;
+}
+
+extern "C" int tgis_decode_advance(const int64_t* ids, int64_t* ids_copy, int64_t* position_ids, int64_t* all_input_ids,
+                                   int64_t ld_all, int32_t* cu_seqlens, const int32_t* cu_seqlens_q, int64_t* stage_ids,
+                                   int32_t* stage_positions, int64_t B, void* stream) {
+    TGIS_CHECK_ARG(ids && position_ids && B >= 0 && (!all_input_ids || ld_all > 0) && (!cu_seqlens || cu_seqlens_q),
+                   "tgis_decode_advance: bad arguments");
+    if (B == 0) return TGIS_OK;
+    hipLaunchKernelGGL(decode_advance_kernel, dim3((unsigned)cdiv64(B + 1, 64)), dim3(64), 0, (hipStream_t)stream, ids,
+                       ids_copy, position_ids, all_input_ids, ld_all, cu_seqlens, cu_seqlens_q, stage_ids, stage_positions, B);
     TGIS_CHECK_LAUNCH();
     return TGIS_OK;
 }

@@ -320,6 +320,27 @@ class _DecodeGraph:
         self.lm = lm
         self.graph = None
         self.logits = self.ids = self.logprobs = None
+        # greedy ids (int64) and their logprobs (f32) in ONE device buffer: one copy to the (pinned) host mirror per step
+        self.out_buf = torch.zeros(B * 12, dtype=torch.uint8, device=dev)
+        self.ids_buf = self.out_buf[:B * 8].view(torch.int64)
+        self.lps_buf = self.out_buf[B * 8:].view(torch.float32)
+        self.host_buf = torch.zeros(B * 12, dtype=torch.uint8).pin_memory()
+        self.host_ready = torch.cuda.Event()
+        # whose next-step inputs the static buffers already hold (tgis_decode_advance wrote them): identity of the
+        # batch's tensors, so that a pruned / concatenated / other batch always stages its own
+        self.staged_ids = self.staged_pos = self.staged_bt = None
+
+    def fetch_greedy(self):
+        """ids and logprobs of the step that just ran, as host lists: one device->host copy, one wait."""
+        self.host_buf.copy_(self.out_buf, non_blocking=True)
+        self.host_ready.record()
+        return self._read_host
+
+    def _read_host(self, want_logprobs: bool):
+        self.host_ready.synchronize()
+        B = self.ids_buf.numel()
+        ids = self.host_buf[:B * 8].view(torch.int64).tolist()
+        return ids, (self.host_buf[B * 8:].view(torch.float32).tolist() if want_logprobs else None)
 
     def _step(self):
         lm = self.lm
@@ -327,13 +348,17 @@ class _DecodeGraph:
         kv = KVArgs(cache=lm.kv_cache, block_tables=self.block_tables, ctx_lens=self.ctx, slots=self.slots,
                     max_q_len=1, max_ctx=self.max_ctx, num_splits=self.num_splits)
         logits = lm.model.forward(self.input_ids, self.positions, self.cu_q, self.max_ctx, None, kv)
-        ids, lps = native.argmax_logprob(logits)
+        ids, lps = native.argmax_logprob(logits, ids_out=self.ids_buf, logprob_out=self.lps_buf)
         return logits, ids, lps
 
     def run(self, input_ids, position_ids, block_tables):
-        self.input_ids.copy_(input_ids, non_blocking=True)
-        self.positions.copy_(position_ids, non_blocking=True)
-        self.block_tables.copy_(block_tables, non_blocking=True)
+        if input_ids is not self.staged_ids or position_ids is not self.staged_pos:
+            self.input_ids.copy_(input_ids, non_blocking=True)
+            self.positions.copy_(position_ids, non_blocking=True)
+        if block_tables is not self.staged_bt:
+            self.block_tables.copy_(block_tables, non_blocking=True)
+            self.staged_bt = block_tables
+        self.staged_ids = self.staged_pos = None
         if not self.lm.use_graphs:
             return self._step()
         if self.graph is None:
@@ -541,8 +566,10 @@ class FlashCausalLM(Model):
             generated_tokens, decode_errors = self._process_decode(batch, out, fused)
             input_token_infos = None
 
-        # logical slot bookkeeping of the reference: one more slot per sequence (:457-458)
-        batch.cu_seqlens.add_(batch.cu_seqlens_q)
+        # logical slot bookkeeping of the reference: one more slot per sequence (:457-458); a decode step has done the
+        # addition on the device already (tgis_decode_advance)
+        if first:
+            batch.cu_seqlens.add_(batch.cu_seqlens_q)
         batch.max_seqlen += 1
         return generated_tokens, input_token_infos, decode_errors, forward_time_ns
 
@@ -576,7 +603,7 @@ class FlashCausalLM(Model):
         else:
             self._graphs.move_to_end(key)
         logits, ids, lps = g.run(batch.input_ids, batch.position_ids, batch.block_tables)
-        return logits, (ids, lps)
+        return logits, (ids, lps, g)
 
     def _process_prefill(self, batch: FlashCausalLMBatch, out):
         generated_tokens: List[TokenInfo] = []
@@ -593,7 +620,7 @@ class FlashCausalLM(Model):
     def _process_decode(self, batch: FlashCausalLMBatch, out, fused):
         generated_tokens: List[TokenInfo] = []
         decode_errors: List[GenerateError] = []
-        batch.position_ids += 1  # used as the scatter index in _process_new_tokens
+        # position_ids += 1, the scatter into all_input_ids and cu_seqlens += cu_seqlens_q happen in _process_new_tokens
         batch.input_ids = self._process_new_tokens(batch, out, generated_tokens, decode_errors, None, False, fused)
         return generated_tokens, decode_errors
 
@@ -607,21 +634,37 @@ class FlashCausalLM(Model):
 
         ntc = batch.next_token_chooser
         simple = ntc.is_plain_greedy and not any(r.details.top_n_toks or r.details.ranks for r in batch.requests)
+        graph = fused[2] if fused is not None else None
+        read_host = None
         if simple:
             # one kernel (already part of the decode graph), one device->host copy for the whole batch
-            next_token_ids, next_logprobs = fused if fused is not None else ntc.choose_greedy_fused(logits)
-            if not prefill:
-                next_token_ids = next_token_ids.clone()  # graph output buffer is reused next step
+            next_token_ids, next_logprobs = fused[:2] if fused is not None else ntc.choose_greedy_fused(logits)
+            if graph is not None:
+                read_host = graph.fetch_greedy()  # the copy is on its way while the bookkeeping launch below runs
         else:
             # EOS mask / length penalty, repetition penalty, warpers, argmax or draw, log-softmax at the chosen id:
             # one launch (tgis_warp_sample) and, below, one device->host copy for the whole batch
             next_token_ids, next_logprobs, lse, next_token_scores = ntc.choose_fused(
                 batch.all_input_ids_tensor[:, :batch.max_seqlen], logits)
 
-        batch.all_input_ids_tensor.scatter_(dim=1, index=batch.position_ids[:, None], src=next_token_ids[:, None])
+        if prefill:
+            batch.all_input_ids_tensor.scatter_(dim=1, index=batch.position_ids[:, None], src=next_token_ids[:, None])
+        else:
+            # reference :499 `position_ids += 1`, :533 the scatter, :457 `cu_seqlens.add_`, and the copy of the ids out of
+            # the buffer the next step overwrites — one launch, which also leaves the next step's inputs in the static
+            # buffers of the graph that will run it
+            next_token_ids = native.decode_advance(
+                next_token_ids, batch.position_ids, batch.all_input_ids_tensor, batch.cu_seqlens, batch.cu_seqlens_q,
+                stage_ids=graph.input_ids if graph is not None else None,
+                stage_positions=graph.positions if graph is not None else None)
+            if graph is not None:
+                graph.staged_ids, graph.staged_pos = next_token_ids, batch.position_ids
 
-        ids_host = next_token_ids.tolist()
-        lps_host = next_logprobs.tolist() if any(ntc.return_logprobs) else None
+        if read_host is not None:
+            ids_host, lps_host = read_host(any(ntc.return_logprobs))
+        else:
+            ids_host = next_token_ids.tolist()
+            lps_host = next_logprobs.tolist() if any(ntc.return_logprobs) else None
         for i, request in enumerate(batch.requests):
             try:
                 if not simple and (request.details.top_n_toks or request.details.ranks):

@@ -118,6 +118,7 @@ SIGNATURES = {
     "tgis_gelu": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _vp]),
     "tgis_embedding": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _vp]),
     "tgis_decode_slots": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp]),
+    "tgis_decode_advance": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _vp, _vp, _c_i64, _vp]),
     "tgis_argmax_logprob": (_c_int, [_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _vp, _vp, _vp]),
     "tgis_llama_decode_tail_slab_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64, _c_i64]),
     "tgis_llama_decode_tail_fits": (_c_int, [ctypes.POINTER(TailArgs)]),
@@ -864,6 +865,33 @@ def decode_slots(positions, block_tables, slots, ctx_lens):
     _check(
         load_library().tgis_decode_slots(_ptr(positions), _ptr(block_tables), block_tables.shape[1], _ptr(slots),
                                          _ptr(ctx_lens), B, _stream()), "tgis_decode_slots")
+
+
+def decode_advance(ids, position_ids, all_input_ids=None, cu_seqlens=None, cu_seqlens_q=None, stage_ids=None,
+                   stage_positions=None):
+    """After a decode step (flash_causal_lm.py:457,499,533-535 in one launch): position_ids += 1 in place, the new ids
+    scattered into all_input_ids at the new positions, cu_seqlens += cu_seqlens_q in place; returns a private copy of
+    `ids`.  stage_ids / stage_positions (a decode graph's static inputs) receive the next step's inputs as well."""
+    B = ids.numel()
+    assert ids.dtype == torch.int64 and position_ids.dtype == torch.int64 and position_ids.numel() == B
+    assert ids.is_contiguous() and position_ids.is_contiguous()
+    out = torch.empty_like(ids)
+    ld = 0
+    if all_input_ids is not None:
+        assert all_input_ids.dtype == torch.int64 and all_input_ids.stride(1) == 1 and all_input_ids.shape[0] >= B
+        ld = all_input_ids.stride(0)
+    if cu_seqlens is not None:
+        assert cu_seqlens.dtype == torch.int32 and cu_seqlens_q.dtype == torch.int32
+        assert cu_seqlens.numel() == B + 1 and cu_seqlens_q.numel() == B + 1
+    if stage_ids is not None:
+        assert stage_ids.dtype == torch.int64 and stage_ids.numel() == B
+    if stage_positions is not None:
+        assert stage_positions.dtype == torch.int32 and stage_positions.numel() == B
+    _check(
+        load_library().tgis_decode_advance(_ptr(ids), _ptr(out), _ptr(position_ids), _ptr(all_input_ids), ld,
+                                           _ptr(cu_seqlens), _ptr(cu_seqlens_q), _ptr(stage_ids), _ptr(stage_positions),
+                                           B, _stream()), "tgis_decode_advance")
+    return out
 
 
 def argmax_logprob(logits, ids_out=None, logprob_out=None):
