@@ -337,9 +337,12 @@ int tgis_decode_advance(const int64_t* ids, int64_t* ids_copy, int64_t* position
 
 /* ---- greedy sampling (Greedy + log_softmax + gather, utils/tokens.py:44-46,238-271,388-397) ------ */
 /* Per row: token = argmax (lowest id on ties), logprob = logit[token] - logsumexp(row).
- * logits [B,V] f32 (logits_f32 != 0) or model dtype. ids_out int64 [B], logprob_out f32 [B]. */
+ * logits [B,V] f32 (logits_f32 != 0) or model dtype. ids_out int64 [B], logprob_out f32 [B].
+ * scratch (may be NULL): tgis_argmax_scratch_bytes(B) bytes of device memory the call may use until it completes; with it
+ * a small batch's rows are split over several workgroups each (two launches; same ids, logprobs within summation order). */
+int64_t tgis_argmax_scratch_bytes(int64_t B);
 int tgis_argmax_logprob(const void* logits, int64_t ld, int64_t B, int64_t V, int logits_f32, int dtype,
-                        int64_t* ids_out, float* logprob_out, void* stream);
+                        int64_t* ids_out, float* logprob_out, void* scratch, int64_t scratch_bytes, void* stream);
 
 /* ---- next-token chooser for a heterogeneous batch -------------------------------------------------
  * One launch for what HeterogeneousNextTokenChooser.__call__ (utils/tokens.py:242-270) does with the

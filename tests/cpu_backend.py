@@ -150,7 +150,7 @@ def _decode_slots(positions, block_tables, slots, ctx_lens):
         ctx_lens[b] = p + 1
 
 
-def _argmax_logprob(logits, ids_out=None, logprob_out=None):
+def _argmax_logprob(logits, ids_out=None, logprob_out=None, scratch=None):
     return ops_ref.greedy(logits)
 
 

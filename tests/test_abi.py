@@ -62,6 +62,6 @@ def test_argument_validation_needs_no_gpu():
     none = [None] * 6
     rc = lib.tgis_warp_sample(None, 0, None, 0, 1, 10, *none, 0, 0, -1, None, -1, None, None, None, None, None, None)
     assert rc == -1 and b"tgis_warp_sample" in lib.tgis_last_error()
-    rc = lib.tgis_argmax_logprob(None, 0, 1, 10, 1, 0, None, None, None)
+    rc = lib.tgis_argmax_logprob(None, 0, 1, 10, 1, 0, None, None, None, 0, None)
     assert rc == -1 and b"tgis_argmax_logprob" in lib.tgis_last_error()
     lib.tgis_clear_error()

@@ -419,6 +419,27 @@ def test_argmax_logprob(nat, gpu_device, dtype):
     _close(lp, wl, rtol=1e-5, atol=1e-5, what="logprob")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,V", [(32, 32000), (16, 32000), (1, 49152), (3, 1000), (200, 32000), (7, 50257)])
+def test_argmax_logprob_rows_split_over_workgroups(nat, gpu_device, dtype, B, V):
+    """With the scratch buffer the rows of a small batch are split over several workgroups (two launches): same ids as the
+    one-workgroup-per-row form and as the oracle, ties across a segment boundary included."""
+    g = torch.Generator().manual_seed(B + V)
+    logits = (torch.randn(B, V, generator=g) * 3).to(dtype)
+    r = B // 2
+    logits[r, V - 1] = logits[r, 3] = logits[r].max() + 1  # a tie between the first and the last segment
+    if B > 2:
+        logits[0, V // 2 + 11] = logits[0].max() + 2       # a winner in a middle segment
+    dev = logits.to(gpu_device)
+    ids0, lp0 = nat.argmax_logprob(dev)
+    ids1, lp1 = nat.argmax_logprob(dev, scratch=nat.argmax_scratch(B, gpu_device))
+    wi, wl = ops_ref.greedy(logits)
+    assert torch.equal(ids1, ids0) and torch.equal(ids1.cpu(), wi)
+    assert int(ids1[r]) == 3
+    _close(lp1, wl, rtol=1e-5, atol=1e-5, what="logprob (split rows)")
+    _close(lp1, lp0, rtol=1e-5, atol=1e-5, what="split vs one workgroup per row")
+
+
 # ---- deferred split-K reduce: GEMM leaves fp32 slabs, the consumer kernel finishes the sum -----------------------
 @pytest.mark.parametrize("M,K,N", [(32, 4096, 4096), (5, 11008, 4096), (1, 256, 64), (64, 4096, 4096), (40, 11008, 4096),
                                    (100, 4096, 4096)])

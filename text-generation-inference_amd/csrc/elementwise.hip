@@ -149,6 +149,100 @@ __global__ __launch_bounds__(1024) void argmax_logprob_kernel(const T* __restric
     }
 }
 
+// The same result from SEG workgroups per row (one workgroup streams a row at what one CU can take in, ~5 us for
+// 32000 fp32 logits; decode batches have far fewer rows than the chip has CUs): part 1 leaves {max, its lowest index,
+// sum exp(l - max)} of each segment, part 2 merges the SEG records of a row.
+struct ArgmaxPart {
+    float m, s;
+    int idx, pad;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_part_kernel(const T* __restrict__ logits, int64_t ld, int64_t V, int seg_len,
+                                                          ArgmaxPart* __restrict__ parts) {
+    __shared__ float sm[4];
+    __shared__ int si[4];
+    __shared__ float ss[4];
+    const int64_t row = blockIdx.y;
+    const int seg = blockIdx.x;
+    const int64_t lo = (int64_t)seg * seg_len, hi = min(V, lo + seg_len);
+    const T* p = logits + row * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        float v = (float)p[i];
+        if (v > best || (v == best && (int)i < bi)) {
+            best = v;
+            bi = (int)i;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        sm[w] = best;
+        si[w] = bi;
+    }
+    __syncthreads();
+    best = sm[0];
+    bi = si[0];
+    for (int k = 1; k < 4; ++k) {
+        if (sm[k] > best || (sm[k] == best && si[k] < bi)) {
+            best = sm[k];
+            bi = si[k];
+        }
+    }
+    float s = 0.f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) s += __expf((float)p[i] - best);  // second pass: cache-resident
+    s = wave_sum(s);
+    if (lane == 0) ss[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ArgmaxPart r;
+        r.m = best;  // -inf and idx 0x7fffffff for an empty segment: loses every comparison, adds exp(-inf) = 0
+        r.s = lo < hi ? ss[0] + ss[1] + ss[2] + ss[3] : 0.f;
+        r.idx = bi;
+        r.pad = 0;
+        parts[row * gridDim.x + seg] = r;
+    }
+}
+
+__global__ __launch_bounds__(64) void argmax_merge_kernel(const ArgmaxPart* __restrict__ parts, int nseg, int64_t B,
+                                                          int64_t* __restrict__ ids, float* __restrict__ logprob) {
+    const int64_t row = blockIdx.x;
+    const int lane = threadIdx.x;
+    float m = -INFINITY, s = 0.f;
+    int idx = 0x7fffffff;
+    if (lane < nseg) {
+        const ArgmaxPart r = parts[row * nseg + lane];
+        m = r.m, s = r.s, idx = r.idx;
+    }
+    float best = m;
+    int bi = idx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    float t = lane < nseg && s > 0.f ? s * __expf(m - best) : 0.f;
+    t = wave_sum(t);
+    if (lane == 0) {
+        ids[row] = bi;
+        logprob[row] = -__logf(t);
+    }
+}
+
 }  // namespace
 
 extern "C" int tgis_act_mul(const void* gate_up, void* out, int64_t T, int64_t I, int act, int dtype,
@@ -225,12 +319,33 @@ extern "C" int tgis_decode_advance(const int64_t* ids, int64_t* ids_copy, int64_
     return TGIS_OK;
 }
 
+extern "C" int64_t tgis_argmax_scratch_bytes(int64_t B) { return B > 0 ? (int64_t)sizeof(ArgmaxPart) * B * 16 : 0; }
+
 extern "C" int tgis_argmax_logprob(const void* logits, int64_t ld, int64_t B, int64_t V, int logits_f32,
-                                   int dtype, int64_t* ids_out, float* logprob_out, void* stream) {
+                                   int dtype, int64_t* ids_out, float* logprob_out, void* scratch, int64_t scratch_bytes,
+                                   void* stream) {
     TGIS_CHECK_ARG(logits && ids_out && logprob_out && V > 0, "tgis_argmax_logprob: bad arguments");
     if (B == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
     TgisTimedScope timed(TGIS_OP_SAMPLE, st);
+    TGIS_CHECK_ARG(logits_f32 || dtype == TGIS_F16 || dtype == TGIS_BF16, "tgis_argmax_logprob: bad dtype");
+    // rows are split over workgroups while the batch leaves most of the chip idle and the caller lent the scratch
+    int nseg = (int)std::min<int64_t>(16, 256 / std::max<int64_t>(B, 1));
+    while (nseg > 1 && cdiv64(V, nseg) < 1024) --nseg;
+    if (scratch && nseg > 1 && scratch_bytes >= (int64_t)sizeof(ArgmaxPart) * B * nseg) {
+        const int seg_len = (int)cdiv64(V, nseg);
+        ArgmaxPart* parts = (ArgmaxPart*)scratch;
+        dim3 grid((unsigned)nseg, (unsigned)B);
+        if (logits_f32)
+            hipLaunchKernelGGL(argmax_part_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, ld, V, seg_len, parts);
+        else if (dtype == TGIS_F16)
+            hipLaunchKernelGGL(argmax_part_kernel<f16>, grid, dim3(256), 0, st, (const f16*)logits, ld, V, seg_len, parts);
+        else
+            hipLaunchKernelGGL(argmax_part_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)logits, ld, V, seg_len, parts);
+        hipLaunchKernelGGL(argmax_merge_kernel, dim3((unsigned)B), dim3(64), 0, st, parts, nseg, B, ids_out, logprob_out);
+        TGIS_CHECK_LAUNCH();
+        return TGIS_OK;
+    }
     dim3 grid((unsigned)B), block(1024);
     if (logits_f32)
         hipLaunchKernelGGL(argmax_logprob_kernel<float>, grid, block, 0, st, (const float*)logits, ld, V, ids_out,

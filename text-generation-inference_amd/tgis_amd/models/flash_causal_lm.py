@@ -324,6 +324,7 @@ class _DecodeGraph:
         self.out_buf = torch.zeros(B * 12, dtype=torch.uint8, device=dev)
         self.ids_buf = self.out_buf[:B * 8].view(torch.int64)
         self.lps_buf = self.out_buf[B * 8:].view(torch.float32)
+        self.argmax_scratch = native.argmax_scratch(B, dev)
         self.host_buf = torch.zeros(B * 12, dtype=torch.uint8).pin_memory()
         self.host_ready = torch.cuda.Event()
         # whose next-step inputs the static buffers already hold (tgis_decode_advance wrote them): identity of the
@@ -348,7 +349,7 @@ class _DecodeGraph:
         kv = KVArgs(cache=lm.kv_cache, block_tables=self.block_tables, ctx_lens=self.ctx, slots=self.slots,
                     max_q_len=1, max_ctx=self.max_ctx, num_splits=self.num_splits)
         logits = lm.model.forward(self.input_ids, self.positions, self.cu_q, self.max_ctx, None, kv)
-        ids, lps = native.argmax_logprob(logits, ids_out=self.ids_buf, logprob_out=self.lps_buf)
+        ids, lps = native.argmax_logprob(logits, ids_out=self.ids_buf, logprob_out=self.lps_buf, scratch=self.argmax_scratch)
         return logits, ids, lps
 
     def run(self, input_ids, position_ids, block_tables):

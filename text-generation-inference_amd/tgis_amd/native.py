@@ -119,7 +119,8 @@ SIGNATURES = {
     "tgis_embedding": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _vp]),
     "tgis_decode_slots": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp]),
     "tgis_decode_advance": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _vp, _vp, _c_i64, _vp]),
-    "tgis_argmax_logprob": (_c_int, [_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _vp, _vp, _vp]),
+    "tgis_argmax_logprob": (_c_int, [_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _c_i64, _vp]),
+    "tgis_argmax_scratch_bytes": (_c_i64, [_c_i64]),
     "tgis_llama_decode_tail_slab_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64, _c_i64]),
     "tgis_llama_decode_tail_fits": (_c_int, [ctypes.POINTER(TailArgs)]),
     "tgis_llama_decode_tail": (_c_int, [ctypes.POINTER(TailArgs), _vp]),
@@ -894,7 +895,12 @@ def decode_advance(ids, position_ids, all_input_ids=None, cu_seqlens=None, cu_se
     return out
 
 
-def argmax_logprob(logits, ids_out=None, logprob_out=None):
+def argmax_scratch(B: int, device) -> torch.Tensor:
+    """Scratch that lets argmax_logprob split the rows of a small batch over several workgroups each."""
+    return torch.empty(max(16, load_library().tgis_argmax_scratch_bytes(B)), dtype=torch.uint8, device=device)
+
+
+def argmax_logprob(logits, ids_out=None, logprob_out=None, scratch=None):
     assert logits.dim() == 2 and logits.stride(1) == 1
     B, V = logits.shape
     if ids_out is None:
@@ -905,7 +911,8 @@ def argmax_logprob(logits, ids_out=None, logprob_out=None):
     _check(
         load_library().tgis_argmax_logprob(_ptr(logits), logits.stride(0), B, V, int(f32),
                                            0 if f32 else dtype_code(logits.dtype), _ptr(ids_out),
-                                           _ptr(logprob_out), _stream()), "tgis_argmax_logprob")
+                                           _ptr(logprob_out), _ptr(scratch), scratch.numel() if scratch is not None else 0,
+                                           _stream()), "tgis_argmax_logprob")
     return ids_out, logprob_out
 
 
