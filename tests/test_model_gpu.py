@@ -423,6 +423,56 @@ def test_graph_pool_outlives_the_eviction_of_its_last_graph(gpu_device):
         assert np.array_equal(a, b), f"step {i}: replay after an eviction differs from the eager step"
 
 
+def test_two_batches_interleaved_on_one_decode_graph_and_a_prune_between_steps(gpu_device):
+    """tgis_decode_advance leaves a batch's next inputs in the static buffers of the graph that ran it, and the next run skips
+    its own staging when the batch's tensors are the ones it staged.  Two batches of one size share a graph: stepped
+    alternately (and one of them pruned half-way, which replaces its tensors), every step's logits, ids, positions,
+    all_input_ids and cu_seqlens must equal those of the same schedule run eagerly."""
+    cfg = TinyLlamaConfig(max_position_embeddings=512)
+    tensors = tiny_llama_tensors(cfg, seed=11, quantize="gptq", groupsize=64)
+    rng = np.random.default_rng(5)
+    pa = [rng.integers(3, cfg.vocab_size, size=n).tolist() for n in (17, 33, 8)]
+    pb = [rng.integers(3, cfg.vocab_size, size=n).tolist() for n in (25, 6, 40)]
+
+    def run(lm, tok):
+        rec = []
+        ta = _LogitTap(lm)
+        a = _from_pb(lm, tok, _pb(pa, 12, first_id=0, batch_id=0))
+        b = _from_pb(lm, tok, _pb(pb, 12, first_id=10, batch_id=1))
+        _step(lm, a, ta, first=True)
+        _step(lm, b, ta, first=True)
+
+        def snap(batch, toks, logits):
+            torch.cuda.synchronize()
+            rec.append((logits.copy(), [t.token_id for t in toks], batch.position_ids.cpu().numpy().copy(),
+                        batch.all_input_ids_tensor.cpu().numpy().copy(), batch.cu_seqlens.cpu().numpy().copy(),
+                        batch.input_ids.cpu().numpy().copy()))
+
+        for i in range(3):
+            for batch in (a, b, b, a):  # same graph key: (3 rows, same table width)
+                snap(batch, *_step(lm, batch, ta))
+        with lm.context_manager():
+            a = lm.batch_type.prune(a, [1])  # request 1 completed: rows 0 and 2 stay, in new tensors
+        c = _from_pb(lm, tok, _pb(pb[:2], 12, first_id=20, batch_id=2))  # two rows as well: shares the pruned batch's graph
+        _step(lm, c, ta, first=True)
+        for i in range(3):
+            for batch in (a, c, b):
+                snap(batch, *_step(lm, batch, ta))
+        for batch in (a, b, c):
+            batch.release()
+        return rec
+
+    lm, tok = _build(cfg, tensors, "gptq", 64, torch.float16, use_graphs=True)
+    got = run(lm, tok)
+    assert lm.use_graphs and 1 <= len(lm._graphs) <= 3
+    lm_e, tok_e = _build(cfg, tensors, "gptq", 64, torch.float16, use_graphs=False)
+    want = run(lm_e, tok_e)
+    assert len(got) == len(want) == 21
+    for i, (g, w) in enumerate(zip(got, want)):
+        for name, x, y in zip(("logits", "ids", "position_ids", "all_input_ids", "cu_seqlens", "input_ids"), g, w):
+            assert np.array_equal(np.asarray(x), np.asarray(y)), f"step {i}: {name} differ between graph replay and eager"
+
+
 def test_captured_graphs_survive_table_and_workspace_growth(gpu_device):
     """Decode graphs hold raw device pointers to the rope tables and to the shared workspace.  Capture a short-context
     graph, then serve a 2100-token request (rope tables grow past their first 2048 positions) and grow the workspace,
