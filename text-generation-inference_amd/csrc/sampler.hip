@@ -319,6 +319,241 @@ __global__ __launch_bounds__(NT) void warp_sample_kernel(SampleArgs a) {
     }
 }
 
+
+// The same chooser with the row in registers (V <= NPT * 1024): after the EOS / repetition-penalty / temperature pass has
+// written the row once (the penalty is a scatter), thread t loads elements t, t + 1024, ... — the very elements the loops
+// above hand it — and every later pass (4 histogram passes, 2 x 32 masked sums, maxima, sums, the draw) runs on those
+// registers; the probabilities of the top-p / typical-p searches are computed once per search instead of once per bit.
+// Same per-thread element order, same expressions, same block reductions: bit-identical to warp_sample_kernel, which stays
+// for larger vocabularies.  (The global form re-read the 128 KB row from L2 ~80 times: 0.4 ms per step at V = 32000.)
+template <int NPT>
+__global__ __launch_bounds__(NT) void warp_sample_reg_kernel(SampleArgs a) {
+    __shared__ float fbuf[NW];
+    __shared__ int ibuf[NW];
+    __shared__ int hist[256];
+    __shared__ uint32_t bc[2];
+    const int b = blockIdx.x, tid = threadIdx.x, V = a.V;
+    Block blk{fbuf, ibuf, tid & 63, tid >> 6};
+    const float* in = a.logits + (int64_t)b * a.ld_logits;
+    float* s = a.scores + (int64_t)b * a.ld_scores;
+    const float NEG_INF = -INFINITY;
+
+    const float T = a.temperature ? a.temperature[b] : 1.0f;
+    int eos_mode = 0;
+    float eos_factor = 0.f;
+    if (a.eos_adjust) {
+        eos_mode = (int)a.eos_adjust[2 * b];
+        eos_factor = a.eos_adjust[2 * b + 1];
+    }
+    auto adjusted = [&](int i) {
+        float x = in[i];
+        if (eos_mode && i == a.eos_id) x = eos_mode == 1 ? NEG_INF : x + fabsf(x) * eos_factor;
+        return x;
+    };
+    float x[NPT];
+    const float pen = a.rep_penalty ? a.rep_penalty[b] : 1.0f;
+    const bool scatter = pen != 1.0f && a.input_ids;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int i = tid + j * NT;
+        x[j] = i < V ? adjusted(i) / T : NEG_INF;
+    }
+    if (scatter) {
+        // the penalised entries go through the row in memory (any thread may hit any id), then come back into registers
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int i = tid + j * NT;
+            if (i < V) s[i] = x[j];
+        }
+        __syncthreads();
+        const int64_t* ids = a.input_ids + (int64_t)b * a.ld_ids;
+        for (int j = tid; j < a.L; j += NT) {  // duplicates write the same value: each id is penalised once
+            int64_t id = ids[j];
+            if (id < 0 || id >= V || id == a.exclude_id) continue;
+            float v = adjusted((int)id);
+            v = v < 0.f ? v * pen : v / pen;
+            s[id] = v / T;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int i = tid + j * NT;
+            if (i < V) x[j] = s[i];
+        }
+    }
+
+    // ---- top-k ----------------------------------------------------------------------------------------------------
+    int k = a.top_k ? a.top_k[b] : 0;
+    if (k > 0 && k < V) {
+        uint32_t prefix = 0, known = 0;
+        int want = k;
+#pragma unroll 1
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int i = tid; i < 256; i += NT) hist[i] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+                if (tid + j * NT < V) {
+                    uint32_t key = order_key(x[j]);
+                    if ((key & known) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int bin = 255, left = want;
+                for (; bin > 0; --bin) {
+                    if (hist[bin] >= left) break;
+                    left -= hist[bin];
+                }
+                bc[0] = (uint32_t)bin;
+                bc[1] = (uint32_t)left;
+            }
+            __syncthreads();
+            prefix |= bc[0] << shift;
+            known |= 255u << shift;
+            want = (int)bc[1];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+            if (order_key(x[j]) < prefix) x[j] = NEG_INF;
+    }
+
+    // ---- top-p ----------------------------------------------------------------------------------------------------
+    const float cut = a.top_p_cut ? a.top_p_cut[b] : 0.0f;
+    if (cut > 0.0f) {
+        float m = NEG_INF;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) m = fmaxf(m, x[j]);
+        m = blk.max(m);
+        float z = 0.f;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+            if (tid + j * NT < V) z += expf(x[j] - m);
+        z = blk.sum(z);
+        const float inv_z = 1.0f / z;
+        float p[NPT];  // (the keys are three operations away from x: recomputed per bit, the registers go to p)
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) p[j] = tid + j * NT < V ? expf(x[j] - m) * inv_z : 0.f;
+        uint32_t t = 0;
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = t | (1u << bit);
+            float acc = 0.f;
+            uint32_t zb = 0;
+            asm volatile("" : "+v"(zb));  // an opaque zero: keeps the 32 keys from being hoisted out of the bit loop (registers)
+#pragma unroll
+            for (int j = 0; j < NPT; ++j)
+                if (order_key(__uint_as_float(__float_as_uint(x[j]) | zb)) <= cand && tid + j * NT < V) acc += p[j];
+            if (blk.sum(acc) <= cut) t = cand;
+        }
+        const uint32_t top = order_key(m);  // min_tokens_to_keep = 1
+        if (t >= top) t = top - 1;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+            if (order_key(x[j]) <= t) x[j] = NEG_INF;
+    }
+
+    // ---- typical-p ------------------------------------------------------------------------------------------------
+    const float mass = a.typical_p ? a.typical_p[b] : 1.0f;
+    if (mass < 1.0f) {
+        float m = NEG_INF;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) m = fmaxf(m, x[j]);
+        m = blk.max(m);
+        float z = 0.f;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+            if (tid + j * NT < V) z += expf(x[j] - m);
+        z = blk.sum(z);
+        const float log_z = m + logf(z), inv_z = 1.0f / z;
+        float h = 0.f;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            if (tid + j * NT < V && x[j] != NEG_INF) {  // nansum: 0 * -inf terms are skipped
+                float lp = x[j] - log_z;
+                h -= expf(lp) * lp;
+            }
+        }
+        const float ent = blk.sum(h);
+        auto dist_key = [&](float v) { return __float_as_uint(fabsf((log_z - v) - ent)); };  // >= 0: bits are ordered
+        float p[NPT];
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) p[j] = tid + j * NT < V ? expf(x[j] - m) * inv_z : 0.f;
+        uint32_t u = 0;
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = u | (1u << bit);
+            float acc = 0.f;
+            uint32_t zb = 0;
+            asm volatile("" : "+v"(zb));
+#pragma unroll
+            for (int j = 0; j < NPT; ++j)
+                if (dist_key(__uint_as_float(__float_as_uint(x[j]) | zb)) < cand && tid + j * NT < V) acc += p[j];
+            if (blk.sum(acc) < mass) u = cand;
+        }
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+            if (dist_key(x[j]) > u) x[j] = NEG_INF;
+    }
+
+    // the warped scores are an output (top-n tokens and ranks read them); the chosen score is read back from them
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int i = tid + j * NT;
+        if (i < V) s[i] = x[j];
+    }
+
+    // ---- choice + log-softmax of the warped scores at the chosen id ----------------------------------------------
+    float m = NEG_INF;
+    int mi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int i = tid + j * NT;
+        if (i < V && (x[j] > m || (x[j] == m && i < mi))) {
+            m = x[j];
+            mi = i;
+        }
+    }
+    blk.argmax(m, mi);
+    if (mi >= V) mi = 0;  // a row of NaNs: no comparison ever succeeded
+    float z = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+        if (tid + j * NT < V) z += expf(x[j] - m);
+    z = blk.sum(z);
+    const float log_z = m + logf(z);
+    int chosen = mi;
+    float chosen_score = m;
+    if (a.do_sample && a.do_sample[b]) {
+        const uint64_t seed = a.rng[2 * b], offset = a.rng[2 * b + 1];
+        float best = NEG_INF;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int i = tid + j * NT;
+            if (i >= V || x[j] == NEG_INF) continue;
+            float uu = ((float)philox_u32(seed, offset, (uint32_t)i) + 0.5f) * 2.3283064365386963e-10f;  // (0, 1]
+            uu = fminf(uu, 0.99999994f);
+            float g = (x[j] - m) - logf(-logf(uu));  // log(p_i / E_i) up to a constant
+            if (g > best || (g == best && i < bi)) {
+                best = g;
+                bi = i;
+            }
+        }
+        blk.argmax(best, bi);  // (its barriers also order the row's stores above before the read below)
+        if (bi >= V) bi = mi;
+        chosen = bi;
+        chosen_score = s[bi];
+        if (tid == 0) a.rng[2 * b + 1] = offset + 1;
+    }
+    if (tid == 0) {
+        a.next_ids[b] = chosen;
+        a.next_logprob[b] = chosen_score - log_z;
+        a.lse[b] = log_z;
+    }
+}
+
 }  // namespace
 
 extern "C" int tgis_warp_sample(const float* logits, int64_t ld_logits, float* scores, int64_t ld_scores, int64_t B,
@@ -339,7 +574,11 @@ extern "C" int tgis_warp_sample(const float* logits, int64_t ld_logits, float* s
     SampleArgs a{logits, ld_logits, scores, ld_scores, (int)V, temperature, top_k, top_p_cut, typical_p, rep_penalty,
                  input_ids, ld_ids, (int)L, (int)exclude_id, eos_adjust, (int)eos_id, do_sample, rng, next_ids,
                  next_logprob, lse};
-    hipLaunchKernelGGL(warp_sample_kernel, dim3((unsigned)B), dim3(NT), 0, st, a);
+    static const bool no_reg = getenv("TGIS_SAMPLER_GLOBAL_ROWS") != nullptr;  // A / B and test hook
+    if (V <= 32 * NT && !no_reg)
+        hipLaunchKernelGGL(warp_sample_reg_kernel<32>, dim3((unsigned)B), dim3(NT), 0, st, a);
+    else
+        hipLaunchKernelGGL(warp_sample_kernel, dim3((unsigned)B), dim3(NT), 0, st, a);
     TGIS_CHECK_LAUNCH();
     return TGIS_OK;
 }
