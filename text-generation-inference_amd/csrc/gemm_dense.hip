@@ -251,7 +251,8 @@ extern "C" int tgis_dense_rope_ok(int64_t M, int64_t K, int64_t N, int64_t D) {
     // as tgis_gptq_rope_ok: the unsplit plan must still cover the chip
     const DensePlan pl = plan_dense(K, N, M, 2);
     const int64_t blocks = cdiv64(cdiv64(N, 32), pl.TN);
-    return blocks >= 128 ? 1 : 0;
+    static const int64_t min_blocks = getenv("TGIS_ROPE_MIN_BLOCKS") ? atoll(getenv("TGIS_ROPE_MIN_BLOCKS")) : 128;
+    return blocks >= min_blocks ? 1 : 0;
 }
 
 extern "C" int tgis_dense_gemm_rope(const void* x, int64_t ldx, const void* prepared, const void* bias,

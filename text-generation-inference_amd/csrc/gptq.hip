@@ -771,7 +771,8 @@ extern "C" int tgis_gptq_rope_ok(int64_t M, int64_t K, int64_t N, int64_t groups
     // the step; a TP = 8 shard of the 7B qkv, 24 blocks: +2 % on the rank-step; TinyLlama dense, 40 blocks: +-0).
     const GemmPlan pl = plan_gemm(K, N, 2, M);
     const int64_t blocks = cdiv64(cdiv64(N, 32), pl.TN);
-    return blocks >= 128 ? 1 : 0;
+    static const int64_t min_blocks = getenv("TGIS_ROPE_MIN_BLOCKS") ? atoll(getenv("TGIS_ROPE_MIN_BLOCKS")) : 128;
+    return blocks >= min_blocks ? 1 : 0;
 }
 
 extern "C" int tgis_gptq_gemm_rope_f16(const void* x, int64_t ldx, const void* prepared, const void* bias,
