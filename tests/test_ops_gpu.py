@@ -628,6 +628,47 @@ def test_dense_gemm_rope_equals_gemm_then_rope_kv_write(nat, gpu_device, dtype, 
         _close(Vp[s_ & 31], qkv_ref[b, (H + Hkv) * D:].view(Hkv, D), rtol=2 * eps, atol=6 * eps * scale, what="fused v page")
 
 
+@pytest.mark.parametrize("M", [1, 7, 32])
+@pytest.mark.parametrize("K,N,act", [(4096, 1536, 0), (4096, 2048, 2), (2048, 512, 0), (11008, 256, 0)])
+def test_lean_gptq_gemm_against_the_exact_dequantised_product(nat, gpu_device, M, K, N, act):
+    """The experimental lean int4 GEMM (tgis_gptq_gemm_f16_lean / _partial_lean with tgis_xsum_f16 row sums: nibbles go to
+    the MFMA undequantised, zero points and scales are applied per group) against the fp32 product with the dequantised
+    weights of the oracle: it never rounds (q - z) * s to f16, so it must be at least as close as the streaming kernel, and
+    within 2e-3 of the largest output.  One activation channel is an outlier (30 x) on purpose."""
+    gs = 128
+    qw, qz, sc, gi = ops_ref.make_gptq_tensors(K, N, gs, seed=K + N)
+    t = [torch.from_numpy(a).to(gpu_device) for a in (qw, qz, sc)]
+    w = nat.GptqWeight(t[0], t[1], t[2], None, 4, gs, gate_up=act == 2)
+    if not nat.gptq_lean_ok(M, w, act):
+        pytest.skip("shape outside the lean kernel's plan")
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).half()
+    x[:, 5] *= 30.0
+    xd = x.to(gpu_device)
+    xs = nat.xsum(xd)
+    want_xs = torch.stack([x.float().view(M, K // 16, 4, 4)[:, :, :, :2].sum((2, 3)),
+                           x.float().view(M, K // 16, 4, 4)[:, :, :, 2:].sum((2, 3))], -1)
+    _close(xs, want_xs, rtol=1e-5, atol=1e-3, what="row sums (k % 4 < 2 | k % 4 >= 2 of every 16 columns)")
+    ws = nat.Workspace(w.workspace_bytes(M), gpu_device)
+    wd = ops_ref.gptq_dequant(qw, qz, sc, gi, gs).double()
+    ref = x.double() @ wd
+    if act == 2:
+        I = N // 2
+        ref = torch.nn.functional.silu(ref[:, :I].half().float()).half().float() * ref[:, I:].half().float()
+    ref = ref.float()
+    scale = float(ref.abs().max())
+    old = nat.gptq_gemm(xd, w, ws, act=act).float().cpu()
+    new = nat.gptq_gemm_lean(xd, xs, w, ws, act=act).float().cpu()
+    e_old, e_new = float((old - ref).abs().max()) / scale, float((new - ref).abs().max()) / scale
+    assert nat.gptq_lean_status(reset=True) == 0, "a bounded wait inside the kernel gave up"
+    assert e_new < 2e-3 and e_new <= 1.5 * e_old + 2.0 ** -11, f"lean {e_new:.2e} vs streaming {e_old:.2e}"
+    if act == 0:
+        p = nat.gptq_gemm_partial_lean(xd, xs, w)
+        sl = p.slabs[: p.S * 32 * p.ld].view(p.S, 32, p.ld).sum(0)[:M, :N].cpu()
+        assert float((sl - ref).abs().max()) / scale < 1e-4, "fp32 split-K slabs of the lean kernel"
+        assert nat.gptq_lean_status(reset=True) == 0
+
+
 @pytest.mark.parametrize("B", [1, 7, 64, 200])
 def test_decode_advance_equals_the_reference_ops(nat, gpu_device, B):
     """tgis_decode_advance against the reference's statements after a decode step (flash_causal_lm.py:457,499,533-535)."""
