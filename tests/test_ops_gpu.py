@@ -669,6 +669,35 @@ def test_lean_gptq_gemm_against_the_exact_dequantised_product(nat, gpu_device, M
         assert nat.gptq_lean_status(reset=True) == 0
 
 
+def test_per_op_timing_hooks_and_device_info(nat, gpu_device):
+    """tgis_timing_* (HIP events on the op's own stream; bench.py's `roofline` is computed from them) and tgis_device_info."""
+    import ctypes
+
+    lib = nat.load_library()
+    cus, hbm = ctypes.c_int(0), ctypes.c_int64(0)
+    name = ctypes.create_string_buffer(128)
+    lib.tgis_device_info.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, ctypes.c_int]
+    assert lib.tgis_device_info(0, ctypes.byref(cus), ctypes.byref(hbm), name, 128) == 0
+    assert cus.value >= 64 and hbm.value > (16 << 30) and len(name.value) > 0
+    x = torch.randn(32, 4096, device=gpu_device).half()
+    w = torch.ones(4096, device=gpu_device).half()
+    nat.timing_reset()
+    n0, _ = nat.timing_read(nat.OP_NORM)
+    nat.rmsnorm_residual(x, None, w, 1e-5)      # timing off: not counted
+    nat.timing_enable(True)
+    for _ in range(5):
+        nat.rmsnorm_residual(x, None, w, 1e-5)
+    torch.cuda.synchronize()
+    nat.timing_enable(False)
+    nat.rmsnorm_residual(x, None, w, 1e-5)
+    n, ms = nat.timing_read(nat.OP_NORM)
+    assert n0 == 0 and n == 5 and 0.0 < ms < 50.0, (n0, n, ms)
+    n_attn, _ = nat.timing_read(nat.OP_ATTN)
+    assert n_attn == 0
+    nat.timing_reset()
+    assert nat.timing_read(nat.OP_NORM)[0] == 0
+
+
 @pytest.mark.parametrize("B", [1, 7, 64, 200])
 def test_decode_advance_equals_the_reference_ops(nat, gpu_device, B):
     """tgis_decode_advance against the reference's statements after a decode step (flash_causal_lm.py:457,499,533-535)."""
