@@ -444,7 +444,7 @@ __global__ __launch_bounds__(NT) void warp_sample_reg_kernel(SampleArgs a) {
             asm volatile("" : "+v"(zb));  // an opaque zero: keeps the 32 keys from being hoisted out of the bit loop (registers)
 #pragma unroll
             for (int j = 0; j < NPT; ++j)
-                if (order_key(__uint_as_float(__float_as_uint(x[j]) | zb)) <= cand && tid + j * NT < V) acc += p[j];
+                if (order_key(__uint_as_float(__float_as_uint(x[j]) | zb)) <= cand) acc += p[j];  // p is 0 beyond the row
             if (blk.sum(acc) <= cut) t = cand;
         }
         const uint32_t top = order_key(m);  // min_tokens_to_keep = 1
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(NT) void warp_sample_reg_kernel(SampleArgs a) {
             asm volatile("" : "+v"(zb));
 #pragma unroll
             for (int j = 0; j < NPT; ++j)
-                if (dist_key(__uint_as_float(__float_as_uint(x[j]) | zb)) < cand && tid + j * NT < V) acc += p[j];
+                if (dist_key(__uint_as_float(__float_as_uint(x[j]) | zb)) < cand) acc += p[j];
             if (blk.sum(acc) < mass) u = cand;
         }
 #pragma unroll
