@@ -118,11 +118,13 @@ __device__ __forceinline__ void norm_row(const NormPhase& p, const int row, floa
     const T* xb = reinterpret_cast<const T*>(p.xbias);
     __amdgpu_buffer_rsrc_t ry = rsrc_of(p.y), ro = rsrc_of(p.res_out);
     float v[MAXV][8];
+    V8 wv[MAXV];  // the norm weights: asked for with the inputs, not after the row reduction (a second round trip)
     float s2 = 0.f;
 #pragma unroll
     for (int it = 0; it < MAXV; ++it) {
         const int c = threadIdx.x + it * nthreads;
         if (c < nchunk) {
+            wv[it] = ld16<V8>(reinterpret_cast<const T*>(p.weight) + c * 8);
             V8 a;
             if (p.slabs) {
                 f32x4 lo, hi;
@@ -179,10 +181,9 @@ __device__ __forceinline__ void norm_row(const NormPhase& p, const int row, floa
     for (int it = 0; it < MAXV; ++it) {
         const int c = threadIdx.x + it * nthreads;
         if (c < nchunk) {
-            const V8 wv = ld16<V8>(reinterpret_cast<const T*>(p.weight) + c * 8);
             V8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = from_f32<T>((v[it][e] - 0.f) * rstd * to_f32(wv[e]));
+            for (int e = 0; e < 8; ++e) o[e] = from_f32<T>((v[it][e] - 0.f) * rstd * to_f32(wv[it][e]));
             if (SC1)
                 st_sc1(__builtin_bit_cast(u32x4, o), ry, ((int64_t)row * p.hidden + c * 8) * 2);
             else

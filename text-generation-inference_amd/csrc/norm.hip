@@ -59,12 +59,15 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
     const T* xr = PARTIAL ? nullptr : x + row * hidden;
     const T* rr = residual ? residual + row * hidden : nullptr;
     float v[MAXV][8];
+    V8 wvs[MAXV], bvs[MAXV];  // weight / bias: asked for with the inputs, not after the row reductions
     const int nchunk = hidden >> 3;  // hidden % 8 == 0
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int it = 0; it < MAXV; ++it) {
         int c = threadIdx.x + it * NT;
         if (c < nchunk) {
+            wvs[it] = ld16<V8>(weight + c * 8);
+            if (bias) bvs[it] = ld16<V8>(bias + c * 8);
             V8 a;
             if (PARTIAL) {
                 f32x4 lo, hi;
@@ -129,10 +132,10 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
     for (int it = 0; it < MAXV; ++it) {
         int c = threadIdx.x + it * NT;
         if (c < nchunk) {
-            V8 wv = ld16<V8>(weight + c * 8);
+            const V8 wv = wvs[it];
             V8 o;
             if (bias) {
-                V8 bv = ld16<V8>(bias + c * 8);
+                const V8 bv = bvs[it];
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     o[e] = from_f32<T>((v[it][e] - mean) * rstd * to_f32(wv[e]) + to_f32(bv[e]));
