@@ -370,7 +370,9 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     // IB of this thread's items x MB splits are loaded before the first use (one round trip per batch instead of one
     // per split and item); batches are folded with the usual running-maximum rescale.
     constexpr int ITEMS = CH * 16 * (D / 8), THREADS = 64 * NW, ITER = (ITEMS + THREADS - 1) / THREADS;
-    constexpr int IB = ITER < 4 ? ITER : 4, MB = 8 / IB;  // <= 8 records (96 registers) in flight
+    // <= 8 records (96 registers) in flight; the three-chunk (MQA) blocks, one per CU anyway, take 12: their four splits
+    // arrive in one round trip instead of two
+    constexpr int IB = ITER < 4 ? ITER : 4, MB = (CH == 3 && IB == 3 ? 12 : 8) / IB;
     for (int it0 = 0; it0 < ITER; it0 += IB) {
         bool ok[IB];
         int64_t rec0[IB];
