@@ -569,10 +569,12 @@ extern "C" int tgis_attn_num_splits(int64_t B, int Hkv, int H, int64_t max_q_len
         //  B=1 MHA D=128 ctx 2048: 14.1 at 8 splits vs 17.7 at 16; B=4 GQA 4:1 ctx 4096: 19.0 at 8 vs 24.0 at 16)
         ns = std::min<int64_t>(cdiv64(256, base), pages / 16);
     } else if (ch > 1) {
-        // multi-chunk blocks hold three sets of accumulators: one block per CU.  Half a round of them, each wave with
-        // >= 4 pages, beats a full round of thinner ones — the merge of the splits costs 6-8 us whatever they hold
-        // (tools/attn_nw.py, 48 q heads on 1 kv head, B=32 ctx 4096: 25.8 us at 4 splits, 29.0 at 8, 31.7 at 2)
-        ns = std::min<int64_t>(cdiv64(128, base), pages / 16);
+        // multi-chunk blocks hold three sets of accumulators: one block per CU, one wave per SIMD, so the block's time is
+        // its waves' page count (~1 us per page: issue-bound) plus ~12 us.  Their splits are merged by the combine launch,
+        // not in the launch (a last-arriving block reads NS x 24 KB through ONE CU: 2.7 us at 4 splits, 5.4 at 8).
+        // 48 q heads on 1 kv head, B=32 ctx 4096, us (kernel + combine): 26.7 at 4 splits, 25.1 at 6, 25.3 at 8
+        // (in-launch merge: 28.1 / 28.6 / 30.2)
+        ns = std::min<int64_t>(cdiv64(192, base), pages / 16);
     } else {
         ns = cdiv64(512, base);
         ns = std::min<int64_t>(ns, cdiv64(pages, 4));  // at least one page per wave
@@ -724,7 +726,7 @@ static int attn_paged_impl(const void* q, int64_t ld_q, const void* k_pool, cons
         // one launch: the last block of each (sequence, kv head) group merges the splits (no combine launch)
         const int64_t recs = fused_records(B, H, Hkv, num_splits);
         const int64_t groups = B * Hkv * a.HCB;
-        if (groups <= ATTN_COUNTERS && recs * D * 4 < (1ll << 31)) {
+        if (groups <= ATTN_COUNTERS && recs * D * 4 < (1ll << 31) && ch == 1) {
             a.counters = attn_counters(st);
             if (a.counters) a.ws_ml = a.ws_o + recs * D;
         }
