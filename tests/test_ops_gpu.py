@@ -769,10 +769,13 @@ def test_dense_gemm_gate_up_epilogue(nat, gpu_device, dtype, M, K, I):
     assert float(diff.max()) <= 4 * eps * float(lin.float().abs().max()) ** 2 + 1e-3
 
 
-@pytest.mark.parametrize("M,K,I", [(32, 4096, 11008), (3, 256, 48), (40, 512, 1376)])
+@pytest.mark.parametrize("M,K,I", [(32, 4096, 11008), (3, 256, 48), (40, 512, 1376), (64, 8192, 3584), (64, 2048, 1008),
+                                   (33, 1024, 48), (64, 4096, 11008)])
 def test_gptq_gemm_gate_up_epilogue(nat, gpu_device, M, K, I):
     """act=2: fused [gate | up] projection with SiLU(gate)*up in the epilogue (columns interleaved at prepare time),
-    and the dequant path must still return the matrix in checkpoint column order."""
+    and the dequant path must still return the matrix in checkpoint column order.  64-row passes over a narrow matrix
+    (the TP shards: (64, 8192, 3584) is a Llama-2-70B gate_up at TP = 8) run split over k with the activation in the
+    split-K reduce; wide ones keep the epilogue."""
     gs = 128 if K % 128 == 0 else 64
     N = 2 * I
     qw, qz, sc, gi = ops_ref.make_gptq_tensors(K, N, gs, seed=K + I)

@@ -348,6 +348,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_f16_kernel(const float* __r
     }
 }
 
+// The same sum for a gate | up image (tile nt holds gate columns 16 nt .. +15 and the matching up columns), followed by
+// out[m][j] = f16(f16(silu(f16 gate)) * f16 up): the act = 2 epilogue of the GEMM, applied here when the projection ran
+// split over k (64-row passes of a narrow shard: an unsplit block would take in its whole 64 x K activation).
+__global__ __launch_bounds__(256) void splitk_reduce_silu_kernel(const float* __restrict__ slabs,
+                                                                 const f16* __restrict__ bias, f16* __restrict__ out,
+                                                                 int64_t ldo, int M, int N, int NP, int S) {
+    const int half = N >> 1, nt4 = (NP >> 5) * 4;  // per row: NT tiles x 4 groups of 4 gate columns
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int mslab = blockIdx.y;
+    if (idx >= (int64_t)32 * nt4) return;
+    const int m = idx / nt4, q = idx - (int64_t)m * nt4, nt = q >> 2, c4 = (q & 3) * 4;
+    if (mslab * 32 + m >= M) return;
+    f32x4 g = {0, 0, 0, 0}, u = {0, 0, 0, 0};
+    const float* base = slabs + ((int64_t)mslab * S * 32 + m) * NP + nt * 32 + c4;
+    for (int s2 = 0; s2 < S; ++s2) {
+        g += *reinterpret_cast<const f32x4*>(base + (int64_t)s2 * 32 * NP);
+        u += *reinterpret_cast<const f32x4*>(base + (int64_t)s2 * 32 * NP + 16);
+    }
+    f16* o = out + (int64_t)(mslab * 32 + m) * ldo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = nt * 16 + c4 + e;
+        if (j >= half) continue;
+        const float mine = (float)(f16)(g[e] + (bias ? (float)bias[j] : 0.f));
+        const float other = (float)(f16)(u[e] + (bias ? (float)bias[half + j] : 0.f));
+        const float sl = mine / (1.f + __expf(-mine));
+        o[j] = (f16)((float)(f16)sl * other);
+    }
+}
+
 }  // namespace
 
 // shared with gptq_lean.hip (declared in gptq_gemm_body.h)
@@ -600,6 +630,11 @@ static int launch_variant(int mr, dim3 grid, size_t lds, hipStream_t st, const G
     return launch_one<TN, WK, ACT, G64, PERM, 1>(grid, lds, st, a);
 }
 
+static int64_t silu_split_below() {  // blocks of the unsplit plan under which a 64-row SiLU * up projection is split (0: never)
+    static const int64_t v = getenv("TGIS_SILU_SPLIT_BELOW") ? atoll(getenv("TGIS_SILU_SPLIT_BELOW")) : 128;
+    return v;
+}
+
 struct RopeEpi {
     const int32_t *positions, *slots;
     const f16 *cosb, *sinb;
@@ -753,10 +788,32 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
     }
     GemmPlan pl = plan_gemm(K, N, act, M);
     TGIS_CHECK_ARG(cdiv64(M, 32) <= 65535, "tgis_gptq_gemm_f16: M too large for one launch");
+    // SiLU * up of a 64-row pass whose unsplit plan has few blocks (TP shards): every block would take in its whole
+    // 64 x K activation (4-8 x its weights: a 70B gate_up shard at TP = 8, 112 blocks, 34.6 us).  The projection then runs
+    // with the split plan of a plain GEMM and the activation moves into the split-K reduce.
+    bool split_silu = false;
+    if (act == 2 && pl.MR == 2 && cdiv64(cdiv64(N, 32), pl.TN) < silu_split_below()) {
+        const GemmPlan ps = plan_gemm(K, N, 0, M);
+        if (ps.S > 1) {
+            pl = ps;
+            split_silu = true;
+        }
+    }
     int64_t need = 4096 + slab_bytes(M, N, pl.S);
     TGIS_CHECK_ARG(workspace && workspace_bytes >= need, "tgis_gptq_gemm_f16: workspace too small (%ld < %ld)",
                    (long)workspace_bytes, (long)need);
     TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
+    if (split_silu) {
+        float* slabs = (float*)((uint8_t*)workspace + 4096);
+        rc = launch_gptq(x, ldx, prepared, nullptr, perm, out, ldo, M, K, N, groups, 0, slabs, 1, pl, st);
+        if (rc != TGIS_OK) return rc;
+        const int NP = (int)cdiv64(N, 32) * 32;
+        dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 32) * 4, 256), (unsigned)cdiv64(M, 32));
+        hipLaunchKernelGGL(splitk_reduce_silu_kernel, rgrid, dim3(256), 0, st, slabs, (const f16*)bias, (f16*)out, ldo, (int)M,
+                           (int)N, NP, pl.S);
+        TGIS_CHECK_LAUNCH();
+        return TGIS_OK;
+    }
     return launch_gptq(x, ldx, prepared, bias, perm, out, ldo, M, K, N, groups, act,
                        (float*)((uint8_t*)workspace + 4096), 0, pl, st);
 }
