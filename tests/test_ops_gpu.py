@@ -770,7 +770,7 @@ def test_dense_gemm_gate_up_epilogue(nat, gpu_device, dtype, M, K, I):
 
 
 @pytest.mark.parametrize("M,K,I", [(32, 4096, 11008), (3, 256, 48), (40, 512, 1376), (64, 8192, 3584), (64, 2048, 1008),
-                                   (33, 1024, 48), (64, 4096, 11008)])
+                                   (33, 1024, 48), (64, 4096, 11008), (32, 4096, 1376), (7, 8192, 3584)])
 def test_gptq_gemm_gate_up_epilogue(nat, gpu_device, M, K, I):
     """act=2: fused [gate | up] projection with SiLU(gate)*up in the epilogue (columns interleaved at prepare time),
     and the dequant path must still return the matrix in checkpoint column order.  64-row passes over a narrow matrix

@@ -788,11 +788,13 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
     }
     GemmPlan pl = plan_gemm(K, N, act, M);
     TGIS_CHECK_ARG(cdiv64(M, 32) <= 65535, "tgis_gptq_gemm_f16: M too large for one launch");
-    // SiLU * up of a 64-row pass whose unsplit plan has few blocks (TP shards): every block would take in its whole
-    // 64 x K activation (4-8 x its weights: a 70B gate_up shard at TP = 8, 112 blocks, 34.6 us).  The projection then runs
-    // with the split plan of a plain GEMM and the activation moves into the split-K reduce.
+    // SiLU * up whose unsplit plan has few blocks (TP shards): every block would take in its whole M x K activation
+    // through one CU (2-8 x its weights: a 70B gate_up shard at TP = 8 and 64 rows, 112 blocks, 34.6 us).  The projection
+    // then runs with the split plan of a plain GEMM and the activation moves into the split-K reduce (us, fused -> split:
+    // 64 rows 8192x7168 34.2 -> 24.0, 4096x2752 18.7 -> 11.3; 32 rows 8192x7168 19.0 -> 15.5, 4096x2752 10.8 -> 8.6,
+    // 4096x5504 (86 blocks) 11.2 -> 10.3; from 172 blocks on the epilogue wins: 4096x11008 11.8 vs 17.5).
     bool split_silu = false;
-    if (act == 2 && pl.MR == 2 && cdiv64(cdiv64(N, 32), pl.TN) < silu_split_below()) {
+    if (act == 2 && cdiv64(cdiv64(N, 32), pl.TN) < silu_split_below()) {
         const GemmPlan ps = plan_gemm(K, N, 0, M);
         if (ps.S > 1) {
             pl = ps;
