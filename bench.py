@@ -116,7 +116,7 @@ def cpu_baseline(cfg, quantize, B, ctx, groupsize=128):
     layer(x, x)  # warm-up
     t0 = time.perf_counter()
     reps = 0
-    while reps < 20 and (reps < 2 or time.perf_counter() - t0 < 10.0):
+    while reps < 96 and (reps < 2 or time.perf_counter() - t0 < 12.0):  # ~10 s of CPU work (three steps' worth of layers)
         layer(x, x)
         reps += 1
     t_layer = (time.perf_counter() - t0) / reps
