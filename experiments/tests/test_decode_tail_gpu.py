@@ -12,7 +12,12 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.experimental, pytest.mark.gpu]
+# Model-level driver: it switched FlashLlamaModel to the tail through the TGIS_DECODE_TAIL hooks (_decode_tails /
+# _forward_decode_tail) that round 4 removed from the product's modeling code together with the entry point.  Kept as the
+# record of what was compared (bit-identical logits, ids and KV pages over 24-40 decode steps); to re-run it, check out
+# 169815d (the end of round 3), where the hooks and the test live in the product tree.
+pytest.skip("needs the round-3 modeling hooks (git checkout 169815d)", allow_module_level=True)
 
 
 def _build(cfg_kw, layers, seed, use_tail, monkeypatch, B, L, steps, quantize="gptq", dtype=torch.float16):

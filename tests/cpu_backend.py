@@ -125,14 +125,6 @@ def _attn_paged(q, ld_q, k_pool, v_pool, block_tables, ctx_lens, cu_q, out, B, H
     return out
 
 
-def _attn_decode_rope(qkv, cos, sin, positions, slots, k_pool, v_pool, block_tables, ctx_lens, cu_q, out, B, H, Hkv, D,
-                      rot_dim, max_ctx, scale, num_splits, ws):
-    # by contract: the stand-alone rotary + cache write, then the attention of the rotated q
-    qkv = _rope_kv_write(qkv.clone(), cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, rot_dim)
-    return _attn_paged(qkv, qkv.stride(0), k_pool, v_pool, block_tables, ctx_lens, cu_q, out, B, H, Hkv, D, 1, max_ctx,
-                       scale, num_splits, ws)
-
-
 def _embedding(ids, table, positions=None, pos_table=None, id_offset=0, out=None):
     local = ids - id_offset
     ok = (local >= 0) & (local < table.shape[0])
@@ -163,13 +155,12 @@ def install(monkeypatch):
     for name, fn in dict(
         Workspace=_Workspace, GptqWeight=_GptqWeight, DenseWeight=_DenseWeight, gptq_gemm=_gptq_gemm,
         dense_gemm=_dense_gemm, rmsnorm_residual=_rmsnorm, layernorm_residual=_layernorm,
-        rope_kv_write=_rope_kv_write, rope_kv_write_prefill=_rope_kv_write_prefill, attn_paged=_attn_paged, attn_decode_rope=_attn_decode_rope, embedding=_embedding, decode_slots=_decode_slots,
+        rope_kv_write=_rope_kv_write, rope_kv_write_prefill=_rope_kv_write_prefill, attn_paged=_attn_paged, embedding=_embedding, decode_slots=_decode_slots,
         argmax_logprob=_argmax_logprob, attn_num_splits=lambda *a: 1, attn_workspace_bytes=lambda *a: 0,
         act_mul=lambda gu, I, out=None: ops_ref.silu_mul(gu, I).to(gu.dtype),
         gptq_gemm_partial=lambda x, w, bias=None, act=0: _gptq_gemm(x, w, None, bias=bias, act=act),
         gptq_rope_ok=lambda M, w, D: 1 <= M <= 64 and w.perm is None,
         rope_gemm_ok=lambda M, w, D: 1 <= M <= 64 and getattr(w, "perm", None) is None,
-        gptq_norm_gemm_ok=lambda M, w, act: False,  # (a grid barrier has no CPU stand-in: the two launches run)
         dense_gemm_rope=lambda x, w, bias, cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, out=None: _rope_kv_write(
             _dense_gemm(x, w, None, bias=bias), cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, D),
         gptq_gemm_rope=lambda x, w, bias, cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, out=None: _rope_kv_write(

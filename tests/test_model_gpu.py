@@ -133,27 +133,6 @@ def test_generate_matches_reference_fixture(gpu_device, variant, dtype, scenario
 
 
 @pytest.mark.parametrize("variant", ["dense", "gptq"])
-def test_rope_and_cache_write_inside_the_attention_launch_reproduce_the_fixture(gpu_device, variant, monkeypatch):
-    """TGIS_FUSED_ROPE_ATTN (opt-in: tgis_attn_decode_rope replaces rope_kv_write + attn_paged at decode): same
-    reference ids and logits, step by step, eagerly and from the captured graph."""
-    from tgis_amd.models.custom_modeling import flash_llama_modeling as M
-
-    monkeypatch.setattr(M, "FUSED_ROPE_ATTN", True)
-    meta, steps = load_fixture(f"llama_{variant}_ragged")
-    cfg = _cfg(meta)
-    tensors = tiny_llama_tensors(cfg, seed=meta["seed"], quantize=meta["quantize"], groupsize=meta["groupsize"])
-    for use_graphs in (False, True):
-        lm, tok = _build(cfg, tensors, meta["quantize"], meta["groupsize"], torch.float16, use_graphs)
-        tap = _LogitTap(lm)
-        batch = _from_pb(lm, tok, _pb(meta["prompts"], meta["max_new"]))
-        for i, want in enumerate(steps):
-            toks, logits = _step(lm, batch, tap, first=(i == 0))
-            _check_step(toks, logits, want, torch.float16, f"fused rope, {variant} step {i}")
-            assert [t.token_id for t in toks] == want["ids"].tolist()
-        batch.release()
-
-
-@pytest.mark.parametrize("variant", ["dense", "gptq"])
 def test_continuous_batching_matches_reference_fixture(gpu_device, variant):
     """Prefill A, decode x2, prefill B (for_concat), concatenate, decode x2, prune id 0, decode x2 — the sequence the
     servicer drives (server.py:105-231) — with page-table edits instead of KV copies."""

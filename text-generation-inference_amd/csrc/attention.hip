@@ -770,6 +770,7 @@ extern "C" int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, 
                            max_q_len, max_ctx, scale, dtype, num_splits, workspace, workspace_bytes, stream, nullptr);
 }
 
+#ifdef TGIS_EXPERIMENTS  // experiments/README.md: not part of libtgis_hip.so
 extern "C" int tgis_attn_decode_rope(const void* qkv, int64_t ld_qkv, const float* slabs, int num_slabs, int64_t slab_ld,
                                      const void* bias, const void* cos, const void* sin, const int32_t* positions,
                                      const int32_t* slots, int rot_dim, void* k_pool, void* v_pool,
@@ -790,3 +791,4 @@ extern "C" int tgis_attn_decode_rope(const void* qkv, int64_t ld_qkv, const floa
                            cu_seqlens_q, out, B, H, Hkv, D, 1, max_ctx, scale, dtype, num_splits, workspace,
                            workspace_bytes, stream, &fr);
 }
+#endif  // TGIS_EXPERIMENTS

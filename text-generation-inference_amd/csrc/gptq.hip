@@ -857,6 +857,7 @@ extern "C" int tgis_gptq_gemm_rope_f16(const void* x, int64_t ldx, const void* p
     return launch_gptq(x, ldx, prepared, bias, nullptr, q_out, ldq, M, K, N, groups, 3, nullptr, 0, pl, st, &rope);
 }
 
+#ifdef TGIS_EXPERIMENTS  // experiments/README.md: not part of libtgis_hip.so
 // ---- add + RMSNorm as the first phase of the GEMM behind it -----------------------------------------------------------
 namespace {
 std::mutex g_gemm_bar_mu;
@@ -991,6 +992,8 @@ extern "C" int tgis_gptq_norm_qkv_rope_f16(const tgis_norm_in* norm, const void*
     TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
     return launch_gptq(np.y, K, prepared, bias, nullptr, q_out, ldq, M, K, N, groups, 3, nullptr, 0, pl, st, &rope, &np, bar);
 }
+
+#endif  // TGIS_EXPERIMENTS
 
 extern "C" int64_t tgis_gptq_gemm_partial_bytes(int64_t M, int64_t K, int64_t N) {
     GemmPlan pl = plan_gemm(K, N, 0, M);

@@ -74,24 +74,8 @@ class KVArgs:
     fresh_prefill: bool = False        # every sequence starts at cache position 0: page-wise cache writes
 
 
-# TGIS_DECODE_TAIL=true: decode batches of up to 32 rows run everything between two attention launches as ONE
-# persistent launch (csrc/decode_tail.hip, bit-identical results).  Off by default: measured on cfg3 the launch takes
-# 67 us against 64 us for the seven launches it replaces (profiles/r02_decode_tail.md) — the six grid barriers cost
-# what the saved dispatch ramps and the cross-barrier weight prefetch gain.
-DECODE_TAIL = os.getenv("TGIS_DECODE_TAIL", "false").lower() in ("1", "true")
-# TGIS_FUSED_ROPE_ATTN=true: decode runs the rotary embedding + cache write of the new token in the attention launch's
-# prologue (tgis_attn_decode_rope, bit-identical results).  Off by default: measured slower than the stand-alone
-# rope_kv_write launch in front of tgis_attn_paged on every config (cfg3 5.37 vs 4.92 ms/step, cfg2 1.21 vs 1.15, cfg5
-# 8.52 vs 7.78; tools/attn_fused_bench.py) — the prologue's dependent loads delay every block's first K/V load, and the
-# new token's scattered v stores collide with the same launch's reads of that page.
-FUSED_ROPE_ATTN = os.getenv("TGIS_FUSED_ROPE_ATTN", "false").lower() in ("1", "true")
-# TGIS_FUSED_NORM_GEMM=true: decode steps of up to 32 rows run each add + RMSNorm as the first phase of the int4 GEMM behind
-# it (input_layernorm inside the qkv + rope launch, post_attention_layernorm inside the gate_up launch): row r is normalised
-# by workgroup r, a grid barrier hands the rows over while the weight rings already stream; bit-identical results.  Off by
-# default: measured 1-1.5 us per layer SLOWER than the separate add + RMSNorm launches on every variant of what is
-# requested under the barrier (cfg3: 4.88 vs 4.84 ms/step on one box) — a grid barrier plus a cross-workgroup hand-off
-# costs what a launch boundary costs on this chip.  Needs the GPU to itself (refused under TGIS_ALLOW_SHARED_GPU).
-FUSED_NORM_GEMM = os.getenv("TGIS_FUSED_NORM_GEMM", "false").lower() in ("1", "true")
+# The persistent decode tail, the rope-in-attention launch and the norm-as-a-GEMM-phase launches of rounds 2 and 3 (all
+# measured slower than the launches they replace) live in experiments/, not on this path.
 
 
 class LlamaRMSNorm:
@@ -183,29 +167,9 @@ class FlashLlamaAttention:
                           attn_output, B, H, Hkv, D, kv.max_q_len, kv.max_ctx, self.softmax_scale, kv.num_splits, ws)
         return attn_output
 
-    def decode_attend(self, hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id: int, kv: KVArgs):
-        """Decode step: qkv GEMM, then ONE launch that finishes its split-K sum, rotates q and k, writes the new token's
-        k / v into its page and attends (tgis_attn_decode_rope) — the reference's :251-295 without a launch of its own
-        for the rotary embedding and the cache write."""
-        H, Hkv, D = self.num_heads, self.num_key_value_heads, self.head_size
-        qkv = self.query_key_value(hidden_states, partial=True)
-        B = kv.block_tables.shape[0]
-        attn_output = torch.empty((B, H * D), dtype=hidden_states.dtype, device=hidden_states.device)
-        ws = None
-        if kv.num_splits > 1:
-            from tgis_amd.utils.layers import workspace
-            ws = workspace(hidden_states.device)
-            ws.ensure(native.attn_workspace_bytes(B, H, Hkv, D, kv.num_splits))
-        return native.attn_decode_rope(qkv, cos, sin, position_ids, kv.slots, kv.cache.k_pool(layer_id),
-                                       kv.cache.v_pool(layer_id), kv.block_tables, kv.ctx_lens, cu_seqlens_q,
-                                       attn_output, B, H, Hkv, D, D, kv.max_ctx, self.softmax_scale, kv.num_splits, ws)
-
     def forward(self, hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id: int, kv: KVArgs):
-        if FUSED_ROPE_ATTN and kv.max_q_len == 1 and kv.slots is not None and not kv.fresh_prefill:
-            attn_output = self.decode_attend(hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id, kv)
-        else:
-            qkv = self.project_qkv(hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id, kv)
-            attn_output = self.attend(qkv, cu_seqlens_q, layer_id, kv)
+        qkv = self.project_qkv(hidden_states, cos, sin, position_ids, cu_seqlens_q, layer_id, kv)
+        attn_output = self.attend(qkv, cu_seqlens_q, layer_id, kv)
         # may be a native.Partial: the following fused add+RMSNorm finishes the split-K sum
         return self.o_proj(attn_output, partial=True)
 
@@ -249,46 +213,9 @@ class FlashLlamaLayer:
         self.post_attention_layernorm = LlamaRMSNorm(prefix=f"{prefix}.post_attention_layernorm", weights=weights,
                                                      eps=config.rms_norm_eps)
 
-    def _norm_qkv(self, hidden_states, residual, cos, sin, position_ids, kv: KVArgs):
-        """input_layernorm + qkv + rotary + cache write as one launch, or None when this step / layer does not qualify."""
-        att = self.self_attn
-        lin = att.query_key_value.linear
-        w = getattr(lin, "rope_handle", None)
-        rows = hidden_states.shape[0]
-        if not (FUSED_NORM_GEMM and isinstance(w, native.GptqWeight) and kv.max_q_len == 1 and kv.slots is not None
-                and not kv.fresh_prefill and rows <= 32 and cos.shape[1] * 2 == att.head_size and not FUSED_ROPE_ATTN
-                and self.input_layernorm.weight.dtype == torch.float16
-                and native.rope_gemm_ok(rows, w, att.head_size) and native.gptq_norm_gemm_ok(rows, w, 3)):
-            return None
-        return native.gptq_norm_qkv_rope(hidden_states, residual, self.input_layernorm.weight,
-                                         self.input_layernorm.variance_epsilon, w, lin.bias, cos, sin, position_ids, kv.slots,
-                                         kv.cache.k_pool(self.layer_id), kv.cache.v_pool(self.layer_id), att.num_heads,
-                                         att.num_key_value_heads, att.head_size)
-
-    def _norm_gate_up(self, attn_output, res, kv: KVArgs):
-        """post_attention_layernorm + gate_up + SiLU * up as one launch, or None."""
-        lin = self.mlp.gate_up_proj.linear
-        w = getattr(lin, "q_handle", None)
-        rows = attn_output.shape[0]
-        if not (FUSED_NORM_GEMM and self.mlp.fused_epilogue and isinstance(w, native.GptqWeight) and kv.max_q_len == 1
-                and not kv.fresh_prefill and rows <= 32 and self.post_attention_layernorm.weight.dtype == torch.float16
-                and native.gptq_norm_gemm_ok(rows, w, 2)):
-            return None
-        return native.gptq_norm_gate_up(attn_output, res, self.post_attention_layernorm.weight,
-                                        self.post_attention_layernorm.variance_epsilon, w, lin.bias)
-
     def forward(self, hidden_states, residual, cos, sin, position_ids, cu_seqlens_q, kv: KVArgs):
-        fused = self._norm_qkv(hidden_states, residual, cos, sin, position_ids, kv)
-        if fused is not None:
-            qkv, res = fused
-            attn_output = self.self_attn.o_proj(self.self_attn.attend(qkv, cu_seqlens_q, self.layer_id, kv), partial=True)
-        else:
-            normed_hidden_states, res = self.input_layernorm(hidden_states, residual)
-            attn_output = self.self_attn(normed_hidden_states, cos, sin, position_ids, cu_seqlens_q, self.layer_id, kv)
-        fused = self._norm_gate_up(attn_output, res, kv)
-        if fused is not None:
-            act, attn_res = fused
-            return self.mlp.down_proj(act, partial=True), attn_res
+        normed_hidden_states, res = self.input_layernorm(hidden_states, residual)
+        attn_output = self.self_attn(normed_hidden_states, cos, sin, position_ids, cu_seqlens_q, self.layer_id, kv)
         normed_attn_res_output, attn_res = self.post_attention_layernorm(attn_output, res)
         mlp_output = self.mlp(normed_attn_res_output)
         return mlp_output, attn_res
@@ -309,65 +236,6 @@ class FlashLlamaModel:
         self.num_heads = self.layers[0].self_attn.num_heads
         self.num_key_value_heads = config.num_key_value_heads // process_group.size()
         self.max_positions = 0
-        self._tails = None  # per layer native.DecodeTail, built at the first decode step that can use them
-
-    # ---- persistent decode tail (csrc/decode_tail.hip) --------------------------------------------------------------
-    def _decode_tails(self, rows: int):
-        """One native.DecodeTail per layer, or False when this model / batch cannot use them (tensor parallel shards
-        have an all-reduce between the phases; dense, act-order or wide-plan linears keep the separate launches)."""
-        if self._tails is None:
-            self._tails = self._build_decode_tails() if DECODE_TAIL and self.tp_world_size == 1 else False
-        if self._tails is False or rows > 32:
-            return False
-        return self._tails
-
-    def _build_decode_tails(self):
-        def image(lin):
-            """(weight image, bias) of a linear the tail can run: an un-permuted int4 image or a dense one."""
-            h = getattr(lin, "q_handle", None)
-            if h is not None:
-                return None if h.perm is not None else (h, lin.bias)
-            d = getattr(lin, "prepared", None)
-            return (d, lin.bias) if isinstance(d, native.DenseWeight) else None
-
-        tails = []
-        for i, layer in enumerate(self.layers):
-            nxt = self.layers[i + 1] if i + 1 < len(self.layers) else None
-            o, gu, down = (image(layer.self_attn.o_proj.linear), image(layer.mlp.gate_up_proj.linear),
-                           image(layer.mlp.down_proj.linear))
-            qkv = image(nxt.self_attn.query_key_value.linear) if nxt is not None else None
-            if None in (o, gu, down) or (nxt is not None and qkv is None):
-                return False
-            dense = isinstance(o[0], native.DenseWeight)
-            kinds = {isinstance(l[0], native.DenseWeight) for l in (o, gu, down, qkv) if l is not None}
-            if kinds != {dense} or (not dense and not layer.mlp.fused_epilogue):
-                return False
-            if not dense and layer.input_layernorm.weight.dtype != torch.float16:
-                return False
-            if not native.decode_tail_fits(32, o[0], gu[0], down[0], qkv[0] if qkv is not None else None):
-                return False
-            att = layer.self_attn
-            tails.append(native.DecodeTail(
-                o, gu, down, layer.post_attention_layernorm.weight,
-                nxt.input_layernorm.weight if nxt is not None else self.norm.weight,
-                layer.post_attention_layernorm.variance_epsilon, qkv=qkv, H=att.num_heads,
-                Hkv=att.num_key_value_heads, D=att.head_size, rot_dim=att.head_size))
-        return tails
-
-    def _forward_decode_tail(self, tails, hidden_states, cos, sin, position_ids, cu_seqlens_q, kv: KVArgs):
-        """embedding -> [norm, qkv, rope] of layer 0 -> per layer: attention launch + one persistent tail launch that
-        ends with the next layer's rotated qkv and cache write (the last one ends with the final norm)."""
-        first = self.layers[0]
-        normed, residual = first.input_layernorm(hidden_states, None)
-        qkv = first.self_attn.project_qkv(normed, cos, sin, position_ids, cu_seqlens_q, 0, kv)
-        for i, (layer, tail) in enumerate(zip(self.layers, tails)):
-            attn_output = layer.self_attn.attend(qkv, cu_seqlens_q, layer.layer_id, kv)
-            last = i + 1 == len(self.layers)
-            hidden_states, residual, qkv = tail.run(
-                attn_output, residual, cos, sin, position_ids, kv.slots,
-                None if last else kv.cache.k_pool(i + 1), None if last else kv.cache.v_pool(i + 1))
-        return hidden_states  # already through the final norm
-
     def rope_tables(self, dtype, device, max_s: int):
         # Sized once for the model's whole position range, so the tables normally never move.  A longer request
         # still works: PositionRotaryEmbedding keeps the replaced tables allocated, because decode graphs captured
@@ -382,10 +250,6 @@ class FlashLlamaModel:
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
         hidden_states = inputs_embeds if inputs_embeds is not None else self.embed_tokens(input_ids)
         cos, sin = self.rope_tables(hidden_states.dtype, hidden_states.device, max_s)
-        if kv.max_q_len == 1 and not kv.fresh_prefill:
-            tails = self._decode_tails(hidden_states.shape[0])
-            if tails:
-                return self._forward_decode_tail(tails, hidden_states, cos, sin, position_ids, cu_seqlens_q, kv)
         residual = None
         for layer in self.layers:
             hidden_states, residual = layer(hidden_states, residual, cos, sin, position_ids, cu_seqlens_q, kv)

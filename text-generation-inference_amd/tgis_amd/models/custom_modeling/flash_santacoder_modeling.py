@@ -108,10 +108,6 @@ class FastLayerNorm:
     __call__ = forward
 
 
-# see flash_llama_modeling.FUSED_ROPE_ATTN
-FUSED_ROPE_ATTN = os.getenv("TGIS_FUSED_ROPE_ATTN", "false").lower() in ("1", "true")
-
-
 class FlashMQAttention:
     def __init__(self, prefix, config, weights):
         self.hidden_size = config.hidden_size
@@ -132,18 +128,6 @@ class FlashMQAttention:
         # the cache-write kernel below (native.Partial)
         qkv = self.c_attn(hidden_states, partial=True)
         k_pool, v_pool = kv.cache.k_pool(layer_id), kv.cache.v_pool(layer_id)
-        if FUSED_ROPE_ATTN and kv.max_q_len == 1 and kv.slots is not None and not kv.fresh_prefill:
-            # decode: the split-K sum, the cache write of the new token and the attention in ONE launch (no rotary here)
-            B = kv.block_tables.shape[0]
-            attn_output = torch.empty((B, H * D), dtype=hidden_states.dtype, device=hidden_states.device)
-            ws = None
-            if kv.num_splits > 1:
-                ws = workspace(hidden_states.device)
-                ws.ensure(native.attn_workspace_bytes(B, H, 1, D, kv.num_splits))
-            native.attn_decode_rope(qkv, None, None, None, kv.slots, k_pool, v_pool, kv.block_tables, kv.ctx_lens,
-                                    cu_seqlens_q, attn_output, B, H, 1, D, D, kv.max_ctx, self.softmax_scale,
-                                    kv.num_splits, ws)
-            return self.c_proj(attn_output, partial=True)
         if kv.fresh_prefill and not isinstance(qkv, native.Partial):
             qkv = native.rope_kv_write_prefill(qkv, None, None, None, cu_seqlens_q, kv.block_tables, k_pool, v_pool,
                                                kv.max_q_len, H, 1, D, D)  # no rotary: page-wise cache write only

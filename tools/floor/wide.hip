@@ -1,0 +1,433 @@
+// Round 4: the int4 decode GEMM re-cut from its byte budget instead of from the round-1 kernel.
+//   - a wave owns CT 32-column tiles (not one) over its own k-range and takes the activation straight from L2 into the MFMA
+//     A operand (16 bytes per lane per MFMA, 64 contiguous bytes per lane per k64-step, shared by the CT tiles): no LDS
+//     staging, no chunk hand-offs, no barrier until the k-part sum at the very end;
+//   - WK waves of a block split k; their fp32 sums meet once in LDS (distributed finish, fixed order);
+//   - DEPTH k64-steps of weights + scales + activation in flight per wave, refilled in place.
+// Same prepared image as libtgis_hip.so (tgis_gptq_prepare): wq[NT][KS][64 lanes][4] u32, sz[NT][G][32] {scale, 1024+z+1}.
+// Self-contained: builds random images, checks sampled columns against a CPU sum, times cold weights (rotating sets).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/floor/wide tools/floor/wide.hip && tools/floor/wide
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define PIN_SGPR(p) asm volatile("" : "+s"(p))
+
+__device__ __forceinline__ uint32_t and_or(uint32_t q, uint32_t mask, uint32_t ex) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(q), "s"(mask), "v"(ex));
+    return r;
+}
+__device__ __forceinline__ f16x8 dequant8(uint32_t q, f16x2 zc, f16x2 zd, f16x2 sc, uint32_t EX, uint32_t M0, uint32_t M1) {
+    const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+    uint32_t q2 = q >> 8;
+    uint32_t a0 = and_or(q, M0, EX), a1 = and_or(q, M1, EX), a2 = and_or(q2, M0, EX), a3 = and_or(q2, M1, EX);
+    f16x2 h0 = (__builtin_bit_cast(f16x2, a0) - zc) * sc;
+    f16x2 h1 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, a1), r16, zd) * sc;
+    f16x2 h2 = (__builtin_bit_cast(f16x2, a2) - zc) * sc;
+    f16x2 h3 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, a3), r16, zd) * sc;
+    u32x4 p = {__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1), __builtin_bit_cast(uint32_t, h2),
+               __builtin_bit_cast(uint32_t, h3)};
+    return __builtin_bit_cast(f16x8, p);
+}
+
+struct Args {
+    const f16* x; int ldx;
+    const f16* xf;         // the same activation in fragment order
+    const uint8_t* prep; int64_t offB;
+    f16* out; int ldo;
+    float* slabs;          // [S][32][NT*32]
+    int M, K, N, NT, KS, G, spg_shift;
+    int S, steps;          // global splits, real k64-steps (K / 64)
+    long long* trace;      // [blocks][WK][8] s_memtime stamps (nullptr: off)
+};
+#define STAMP(i) do { if (TR) { stamp[i] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
+
+// MODE: 0 full; 1 no arithmetic (loads, waits, reduce, stores); 2 no x loads (A = weights); 3 no weight loads beyond prologue
+template <int CT, int WK, int DEPTH, int MODE, int XF = 0, int ORD = 0, bool TR = false>
+__global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cg = blockIdx.x, split = blockIdx.y;
+    // this split's steps, then this wave's share of them (contiguous)
+    const int sp_len = (a.steps + a.S - 1) / a.S;
+    const int sb = split * sp_len, se = min(a.steps, sb + sp_len);
+    const int len = max(se - sb, 0);
+    const int s0 = sb + (len * wk) / WK, s1 = sb + (len * (wk + 1)) / WK;
+    const int mrows = min(32, a.M);
+    long long stamp[8];
+    STAMP(0);
+    if (TR) stamp[7] = __builtin_amdgcn_s_memrealtime();
+
+    const char* wt[CT];
+    const char* st[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int nt = min(cg * CT + t, a.NT - 1);
+        wt[t] = reinterpret_cast<const char*>(a.prep) + (int64_t)nt * a.KS * 1024;
+        st[t] = reinterpret_cast<const char*>(a.prep + a.offB) + (int64_t)nt * a.G * 128;
+    }
+    const uint32_t woff = lane * 16, szoff = (lane & 31) * 4;
+    const int sclamp = max(s1 - 1, s0);
+    const uint32_t xlane = (uint32_t)(min(lane & 31, mrows - 1) * a.ldx * 2 + (lane >> 5) * 64);
+    const char* xb = reinterpret_cast<const char*>(a.x);
+
+    u32x4 wq[DEPTH][CT];
+    uint32_t sz[DEPTH][CT];
+    f16x8 xa[DEPTH][4];
+    auto load_x = [&](int d, int step) {
+        if (XF) {   // fragment-major activation: [step][i][lane][8 halves], 1 KiB per load
+            const char* p = reinterpret_cast<const char*>(a.xf) + (int64_t)min(step, sclamp) * 4096;
+            PIN_SGPR(p);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xa[d][i] = *(const GLOBAL_AS f16x8*)(p + woff + i * 1024);
+            return;
+        }
+        const char* p = xb + (int64_t)min(step, sclamp) * 128;
+        PIN_SGPR(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xa[d][i] = *(const GLOBAL_AS f16x8*)(p + xlane + i * 16);
+    };
+    auto load_sz = [&](int d, int step) {
+        const int g = min(min(step, sclamp) >> a.spg_shift, a.G - 1);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const char* p = st[t] + (int64_t)g * 128;
+            PIN_SGPR(p);
+            const uint32_t v = *(const GLOBAL_AS uint32_t*)(p + szoff);
+            sz[d][t] = step < s1 ? v : 0u;
+        }
+    };
+    auto load_w = [&](int d, int step) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const char* p = wt[t] + (int64_t)min(step, sclamp) * 1024;
+            PIN_SGPR(p);
+            wq[d][t] = __builtin_nontemporal_load((const GLOBAL_AS u32x4*)(p + woff));
+        }
+    };
+
+    uint32_t EXr = 0x64006400u, M0r = 0x000F000Fu, M1r = 0x00F000F0u;
+    asm volatile("" : "+v"(EXr));
+    asm volatile("" : "+s"(M0r), "+s"(M1r));
+    f32x16 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    // prologue.  ORD 0: type-major (all x, all scales, all weights); ORD 1: step-major (what step 0 needs first)
+    if (ORD == 0) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) if (MODE != 2 && (MODE < 4 || MODE > 5)) load_x(d, s0 + d);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) if (MODE != 4) load_sz(d, s0 + d);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) load_w(d, s0 + d);
+    } else {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (MODE != 4) load_sz(d, s0 + d);
+            load_w(d, s0 + d);
+            if (MODE != 2 && (MODE < 4 || MODE > 5)) load_x(d, s0 + d);
+        }
+    }
+
+    auto consume = [&](int d) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const f16x2 szh = __builtin_bit_cast(f16x2, sz[d][t]);
+            const f16 zc1 = szh[1];
+            const f16 zd1 = (f16)960.f - zc1;
+            const f16x2 zc = {zc1, zc1}, zd = {zd1, zd1}, sc = {szh[0], szh[0]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (MODE == 6) {
+                    const u32x4 raw = {wq[d][t][i], wq[d][t][i] ^ EXr, sz[d][t], wq[d][t][i]};
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[d][i], __builtin_bit_cast(f16x8, raw), acc[t], 0, 0, 0);
+                } else if (MODE == 7) {
+                    const f16x8 b = dequant8(wq[d][t][i], zc, zd, sc, EXr, M0r, M1r);
+                    const f16x8 pr = b * xa[d][i];
+                    acc[t][i] += (float)pr[0] + (float)pr[2] + (float)pr[4] + (float)pr[6];
+                } else if (MODE == 4) {
+                    acc[t][i] += __builtin_bit_cast(float, wq[d][t][i]);
+                } else if (MODE == 5) {
+                    acc[t][i] += __builtin_bit_cast(float, wq[d][t][i]) + (float)szh[0];
+                } else if (MODE == 1) {
+                    acc[t][i] += __builtin_bit_cast(float, wq[d][t][i]) + (float)xa[d][i][0] + (float)szh[0];
+                } else {
+                    const f16x8 b = dequant8(wq[d][t][i], zc, zd, sc, EXr, M0r, M1r);
+                    const f16x8 av = MODE == 2 ? __builtin_bit_cast(f16x8, wq[d][(t + 1) % CT]) : xa[d][i];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    STAMP(1);
+    int s = s0;
+    for (; s + DEPTH < s1; s += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            consume(d);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE != 4) load_sz(d, s + d + DEPTH);
+            if (MODE != 3) load_w(d, s + d + DEPTH);
+            if (MODE != 2 && (MODE < 4 || MODE > 5)) load_x(d, s + d + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    STAMP(2);
+    // the last group: only the steps that exist (wave-uniform branches; nothing is loaded any more)
+    if (s < s1) consume(0);
+    STAMP(3);
+#pragma unroll
+    for (int d = 1; d < DEPTH; ++d)
+        if (s + d < s1) consume(d);
+    STAMP(4);
+
+    // ---- k-part sum through LDS, distributed finish: wave wk ends up with registers [wk NR, (wk+1) NR) of every tile ----
+    constexpr int NR = 16 / WK;
+    float* red = reinterpret_cast<float*>(smem);  // [WK][CT][16 registers][64 lanes]: every access is 64 consecutive words
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        float* dst = red + ((wk * CT + t) << 10) + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r << 6] = acc[t][r];
+    }
+    __syncthreads();
+    STAMP(5);
+    float fin[CT][NR];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+#pragma unroll
+        for (int k2 = 0; k2 < WK; ++k2) {
+            const float* src = red + ((k2 * CT + t) << 10) + ((wk * NR) << 6) + lane;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) fin[t][j] = k2 == 0 ? src[j << 6] : fin[t][j] + src[j << 6];
+        }
+    }
+    const int c = lane & 31;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int nt = cg * CT + t;
+        if (nt >= a.NT) break;
+        const int n = nt * 32 + c;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int r = wk * NR + j;
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (a.S == 1) {
+                if (m < mrows && n < a.N) a.out[(int64_t)m * a.ldo + n] = (f16)fin[t][j];
+            } else {
+                a.slabs[((int64_t)split * 32 + m) * (a.NT * 32) + n] = fin[t][j];
+            }
+        }
+    }
+    STAMP(6);
+    if (TR && lane == 0) {
+        long long* tp = a.trace + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WK + wk) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tp[i] = stamp[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+struct Image {
+    int K, N, NT, KS, G, gs;
+    int64_t offB, total;
+    std::vector<uint8_t> host;
+};
+static uint64_t rng_state = 0x1234567ull;
+static inline uint32_t rnd() { rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng_state >> 33); }
+
+static Image make_image(int K, int N, int gs) {
+    Image im;
+    im.K = K; im.N = N; im.gs = gs; im.G = (K + gs - 1) / gs;
+    im.NT = (N + 31) / 32; im.KS = ((K + 255) / 256) * 4 + 1;
+    im.offB = (int64_t)im.NT * im.KS * 1024;
+    im.total = (im.offB + (int64_t)im.NT * im.G * 128 + 255) & ~255ll;
+    im.host.resize(im.total);
+    uint32_t* w = reinterpret_cast<uint32_t*>(im.host.data());
+    for (int64_t i = 0; i < im.offB / 4; ++i) w[i] = rnd() ^ (rnd() << 16);
+    // rows >= K hold zero nibbles in the real image; K is a multiple of 64 here so only whole steps are padding
+    for (int nt = 0; nt < im.NT; ++nt)
+        for (int ks = K / 64; ks < im.KS; ++ks) std::fill_n(w + ((int64_t)nt * im.KS + ks) * 256, 256, 0u);
+    uint32_t* sz = reinterpret_cast<uint32_t*>(im.host.data() + im.offB);
+    for (int64_t i = 0; i < (int64_t)im.NT * im.G * 32; ++i) {
+        f16 s = (f16)(0.005f + 0.01f * (rnd() % 1000) / 1000.f);
+        f16 z = (f16)(1024.f + (rnd() % 14) + 1);
+        uint16_t sb, zb;
+        memcpy(&sb, &s, 2); memcpy(&zb, &z, 2);
+        sz[i] = sb | ((uint32_t)zb << 16);
+    }
+    return im;
+}
+static double ref_dot(const Image& im, const std::vector<f16>& x, int ldx, int m, int n) {
+    static const int order[8] = {0, 2, 4, 6, 1, 3, 5, 7};
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(im.host.data());
+    const uint32_t* sz = reinterpret_cast<const uint32_t*>(im.host.data() + im.offB);
+    const int nt = n / 32, c = n % 32;
+    double s = 0;
+    for (int ks = 0; ks < im.K / 64; ++ks)
+        for (int h = 0; h < 2; ++h)
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t q = w[(((int64_t)nt * im.KS + ks) * 64 + h * 32 + c) * 4 + i];
+                for (int j = 0; j < 8; ++j) {
+                    const int k = ks * 64 + h * 32 + i * 8 + order[j];
+                    const uint32_t e = sz[((int64_t)nt * im.G + k / im.gs) * 32 + c];
+                    uint16_t sb = e & 0xffff, zb = e >> 16;
+                    f16 sc, zc;
+                    memcpy(&sc, &sb, 2); memcpy(&zc, &zb, 2);
+                    const f16 wv = (f16)(((float)((q >> (4 * j)) & 15) + 1024.f - (float)zc) * (float)sc);
+                    s += (double)(float)wv * (double)(float)x[(int64_t)m * ldx + k];
+                }
+            }
+    return s;
+}
+
+static const f16* g_xf = nullptr;
+static int g_ldx = 0;
+template <int CT, int WK, int DEPTH, int MODE, int XF = 0, int ORD = 0>
+static float run(const Image& im, const std::vector<uint8_t*>& sets, const f16* dx, f16* dout, float* dslabs, int M, int S,
+                 int iters, bool check, const std::vector<f16>& hx) {
+    Args a;
+    a.x = dx; a.ldx = g_ldx; a.xf = g_xf; a.out = dout; a.ldo = im.N; a.slabs = dslabs;
+    a.M = M; a.K = im.K; a.N = im.N; a.NT = im.NT; a.KS = im.KS; a.G = im.G;
+    a.offB = im.offB; a.S = S; a.steps = im.K / 64; a.trace = nullptr;
+    int spg = im.gs / 64, sh = 0;
+    while ((1 << sh) < spg) ++sh;
+    a.spg_shift = sh;
+    const int cgs = (im.NT + CT - 1) / CT;
+    const size_t lds = (size_t)WK * CT * 4096;
+    CK(hipFuncSetAttribute((const void*)wide_gemm<CT, WK, DEPTH, MODE, XF, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)wide_gemm<CT, WK, DEPTH, MODE, XF, ORD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid(cgs, S);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) {
+            a.prep = sets[i % sets.size()];
+            hipLaunchKernelGGL((wide_gemm<CT, WK, DEPTH, MODE, XF, ORD>), grid, dim3(64 * WK), lds, 0, a);
+        }
+        CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms * 1000.f / iters);
+    }
+    if (getenv("WIDE_TRACE")) {
+        const int nw = cgs * S * WK;
+        long long* dtr; CK(hipMalloc(&dtr, (size_t)nw * 8 * 8)); CK(hipMemset(dtr, 0, (size_t)nw * 8 * 8));
+        a.trace = dtr;
+        for (int i = 0; i < 4; ++i) {   // the last of a few cold launches
+            a.prep = sets[(i + 3) % sets.size()];
+            hipLaunchKernelGGL((wide_gemm<CT, WK, DEPTH, MODE, XF, ORD, true>), grid, dim3(64 * WK), lds, 0, a);
+        }
+        CK(hipDeviceSynchronize());
+        std::vector<long long> tr((size_t)nw * 8);
+        CK(hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost));
+        long long rt0 = tr[7];
+        for (int i = 0; i < nw; ++i) rt0 = std::min(rt0, tr[(size_t)i * 8 + 7]);
+        {
+            std::vector<long long> v(nw);
+            for (int i = 0; i < nw; ++i) v[i] = (tr[(size_t)i * 8 + 7] - rt0) * 10;
+            std::sort(v.begin(), v.end());
+            printf("    wave entry after the first wave's entry (ns, s_memrealtime): median %lld  p90 %lld  max %lld\n", v[nw / 2], v[nw * 9 / 10], v[nw - 1]);
+        }
+        printf("    trace (s_memtime ticks from the wave's own entry; min / median / max over %d waves):\n", nw);
+        const char* names[7] = {"entry", "prologue issued", "loop done", "first of last group", "last group done", "after barrier", "stored"};
+        for (int k = 0; k < 7; ++k) {
+            std::vector<long long> v(nw);
+            for (int i = 0; i < nw; ++i) v[i] = tr[(size_t)i * 8 + k] - tr[(size_t)i * 8];
+            std::sort(v.begin(), v.end());
+            printf("      %-20s %7lld %7lld %7lld\n", names[k], v[0], v[nw / 2], v[nw - 1]);
+        }
+        a.trace = nullptr;
+        CK(hipFree(dtr));
+    }
+    double maxerr = 0;
+    if (check && MODE == 0) {
+        a.prep = sets[0];
+        CK(hipMemset(dout, 0, (size_t)32 * im.N * 2));
+        hipLaunchKernelGGL((wide_gemm<CT, WK, DEPTH, MODE, XF, ORD>), grid, dim3(64 * WK), lds, 0, a);
+        CK(hipDeviceSynchronize());
+        std::vector<f16> ho((size_t)32 * im.N);
+        std::vector<float> hs;
+        if (S == 1) CK(hipMemcpy(ho.data(), dout, ho.size() * 2, hipMemcpyDeviceToHost));
+        else { hs.resize((size_t)S * 32 * im.NT * 32); CK(hipMemcpy(hs.data(), dslabs, hs.size() * 4, hipMemcpyDeviceToHost)); }
+        for (int t = 0; t < 48; ++t) {
+            const int m = rnd() % M, n = t < 4 ? (t & 1 ? im.N - 1 - (t >> 1) : (t >> 1)) : rnd() % im.N;
+            double got;
+            if (S == 1) got = (float)ho[(size_t)m * im.N + n];
+            else { got = 0; for (int s2 = 0; s2 < S; ++s2) got += hs[((size_t)s2 * 32 + m) * (im.NT * 32) + n]; }
+            const double want = ref_dot(im, hx, im.K, m, n);
+            maxerr = std::max(maxerr, fabs(got - want) / (1.0 + fabs(want)));
+        }
+    }
+    const int blocks = cgs * S;
+    const double mb = (double)(im.offB * 1.0 * (im.K / 64) / im.KS + (double)im.NT * im.G * 128) / 1e6;
+    printf("  CT %d WK %2d DEPTH %d S %2d mode %d xf %d ord %d ldx %d: blocks %4d  %6.2f us  %5.2f TB/s  relerr %.1e%s\n", CT, WK, DEPTH, S, MODE, XF, ORD, g_ldx, blocks, best,
+           mb / best, maxerr, (check && MODE == 0 && maxerr > 3e-3) ? "  <-- WRONG" : "");
+    return best;
+}
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 32;
+    struct Shape { const char* name; int K, N; } shapes[] = {
+        {"qkv 4096x12288", 4096, 12288}, {"o 4096x4096", 4096, 4096}, {"gate_up 4096x22016", 4096, 22016}, {"down 11008x4096", 11008, 4096}};
+    for (auto& sh : shapes) {
+        Image im = make_image(sh.K, sh.N, 128);
+        const int nsets = (int)std::max<int64_t>(2, (700ll << 20) / im.total);
+        std::vector<uint8_t*> sets(nsets);
+        for (int i = 0; i < nsets; ++i) {
+            CK(hipMalloc(&sets[i], im.total));
+            CK(hipMemcpy(sets[i], im.host.data(), im.total, hipMemcpyHostToDevice));
+        }
+        std::vector<f16> hx((size_t)32 * sh.K);
+        for (auto& v : hx) v = (f16)(((int)(rnd() % 2001) - 1000) / 1000.f);
+        f16* dx; CK(hipMalloc(&dx, hx.size() * 2)); CK(hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+        f16* dxp; CK(hipMalloc(&dxp, (size_t)32 * (sh.K + 64) * 2));
+        CK(hipMemcpy2D(dxp, (size_t)(sh.K + 64) * 2, hx.data(), (size_t)sh.K * 2, (size_t)sh.K * 2, 32, hipMemcpyHostToDevice));
+        std::vector<f16> hxf(hx.size());
+        for (int st = 0; st < sh.K / 64; ++st)
+            for (int i = 0; i < 4; ++i)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 8; ++e)
+                        hxf[(((size_t)st * 4 + i) * 64 + l) * 8 + e] = hx[(size_t)(l & 31) * sh.K + st * 64 + (l >> 5) * 32 + i * 8 + e];
+        f16* dxf; CK(hipMalloc(&dxf, hxf.size() * 2)); CK(hipMemcpy(dxf, hxf.data(), hxf.size() * 2, hipMemcpyHostToDevice));
+        g_xf = dxf;
+        f16* dout; CK(hipMalloc(&dout, (size_t)32 * sh.N * 2));
+        float* dslabs; CK(hipMalloc(&dslabs, (size_t)16 * 32 * im.NT * 32 * 4));
+        printf("%s  (%.1f MB image, %d rotating sets, M = %d)\n", sh.name, im.total / 1e6, nsets, M);
+        const int it = 2 * nsets;
+#define R(CT, WK, D, S) (g_ldx = sh.K, run<CT, WK, D, 0, 0, 1>(im, sets, dx, dout, dslabs, M, S, it, true, hx))
+#define RP(CT, WK, D, S) (g_ldx = sh.K + 64, run<CT, WK, D, 0, 0, 1>(im, sets, dxp, dout, dslabs, M, S, it, true, hx))
+#define RX(CT, WK, D, S) (g_ldx = sh.K, run<CT, WK, D, 0, 1, 1>(im, sets, dx, dout, dslabs, M, S, it, true, hx))
+#define RX0(CT, WK, D, S) (g_ldx = sh.K, run<CT, WK, D, 0, 1, 0>(im, sets, dx, dout, dslabs, M, S, it, true, hx))
+#define RM(CT, WK, D, S, MODE) (g_ldx = sh.K, run<CT, WK, D, MODE, 1, 1>(im, sets, dx, dout, dslabs, M, S, it, false, hx))
+        if (sh.N == 12288) {
+            RX(3, 8, 2, 2); RM(3, 8, 2, 2, 6); RM(3, 8, 2, 2, 7); RM(3, 8, 2, 2, 4);
+            RX(2, 16, 2, 1); RX(2, 8, 2, 1); RX(1, 8, 2, 1); RX(1, 16, 2, 1); RX(1, 8, 4, 1); RX(2, 8, 4, 1);
+        } else if (sh.N == 22016) {
+            RX(3, 8, 2, 1); RM(3, 8, 2, 1, 6); RM(3, 8, 2, 1, 7); RM(3, 8, 2, 1, 4);
+        } else if (sh.K == 11008) {
+            RX(2, 8, 2, 4); RM(2, 8, 2, 4, 6); RM(2, 8, 2, 4, 7); RM(2, 8, 2, 4, 4);
+        } else {
+            RX(2, 8, 2, 4); RM(2, 8, 2, 4, 6); RM(2, 8, 2, 4, 7); RM(2, 8, 2, 4, 4);
+        }
+        for (auto p : sets) CK(hipFree(p));
+        CK(hipFree(dx)); CK(hipFree(dout)); CK(hipFree(dslabs));
+    }
+    return 0;
+}
