@@ -95,6 +95,20 @@ int tgis_gptq_prepare(const int32_t* qweight, const int32_t* qzeros, const void*
 int64_t tgis_gptq_gemm_fused_rows(int64_t K, int64_t groups, int act_order, int act);
 int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
 
+/* Activation layout between the decode step's own kernels (round 4).  A leading dimension of TGIS_LD_FRAGMENTS says that a
+ * [M <= 32, K] f16 activation (K % 64 == 0; the buffer holds 32 * K elements whatever M is) is stored in the order the MFMA
+ * reads it — [k64-step][i = k/8 % 4][lane = 32 (k/32 % 2) + row][k % 8], i.e. element (m, k) at
+ * ((k/64 * 4 + k/8 % 4) * 64 + 32 (k/32 % 2) + m) * 8 + k % 8 — instead of row-major.  Producers that can write it:
+ * tgis_rmsnorm_residual[_partial] (ldy), tgis_attn_paged (ld_out), tgis_gptq_gemm_f16 with act = 2 (ldo).  Consumers:
+ * tgis_gptq_gemm_f16, tgis_gptq_gemm_f16_partial, tgis_gptq_gemm_rope_f16 (ldx), which then run the kernel of
+ * csrc/gptq_wide_body.h: each k64-step of the activation is four contiguous KiB straight into the A operand, no LDS staging
+ * (7B shapes, 32 rows: qkv + rope 16.9 -> 12 us, o 6.0 -> 5.3, gate_up 16.8 -> 14.4, down 10.5 -> 9.2).  Same arithmetic as
+ * the row-major path ((q - z) * s rounded to f16 once, fp32 accumulation); only the summation order over k differs.
+ * tgis_gptq_fragments_ok: 1 if the GEMM (act 0, 2, or 3 = the rope epilogue) takes such an activation and is expected to be
+ * faster with it (1 <= M <= 32, no act-order, groups of 64 * 2^n rows; act 2 / 3 additionally >= 128 workgroups). */
+#define TGIS_LD_FRAGMENTS ((int64_t)-32)
+int tgis_gptq_fragments_ok(int64_t M, int64_t K, int64_t N, int64_t groups, int act_order, int act);
+
 /* out[M,N] f16 = x[M,K] f16 @ dequant(W)[K,N] (+ bias[N] f16 if non-NULL); fp32 accumulate.
  * Fused int4-dequant MFMA kernel for any M (rows are processed in slabs of 32).
  * x row stride ldx, out row stride ldo (elements).  perm (int32 [K] or NULL) gathers x columns
@@ -174,15 +188,17 @@ int tgis_dense_gemm_partial(const void* x, int64_t ldx, const void* prepared, in
 /* ---- fused residual-add + RMSNorm / LayerNorm (replaces dropout_layer_norm.dropout_add_ln_fwd,
  *      custom_modeling/flash_llama_modeling.py:132-152, utils/layers.py:376-396) ---------------- */
 /* res_out = x (+ residual); y = res_out * rsqrt(mean(res_out^2) + eps) * weight.
- * residual may be NULL (first layer).  res_out may alias residual or x.  fp32 statistics. */
-int tgis_rmsnorm_residual(const void* x, const void* residual, const void* weight, void* y,
+ * residual may be NULL (first layer).  res_out may alias residual or x.  fp32 statistics.
+ * ldy: 0 or hidden (y row-major), or TGIS_LD_FRAGMENTS (rows <= 32, hidden % 64 == 0: y feeds an int4 GEMM of the decode
+ * step, see TGIS_LD_FRAGMENTS above). */
+int tgis_rmsnorm_residual(const void* x, const void* residual, const void* weight, void* y, int64_t ldy,
                           void* res_out, int64_t rows, int64_t hidden, float eps, int dtype,
                           void* stream);
 /* Same as tgis_rmsnorm_residual with x given as split-K partial sums: x = f16(sum_s slabs[s][row][:] (+ bias)).
  * rows <= 32. */
 int tgis_rmsnorm_residual_partial(const float* slabs, int num_slabs, int64_t slab_ld, const void* bias,
-                                  const void* residual, const void* weight, void* y, void* res_out, int64_t rows,
-                                  int64_t hidden, float eps, int dtype, void* stream);
+                                  const void* residual, const void* weight, void* y, int64_t ldy, void* res_out,
+                                  int64_t rows, int64_t hidden, float eps, int dtype, void* stream);
 int tgis_layernorm_residual(const void* x, const void* residual, const void* weight, const void* bias,
                             void* y, void* res_out, int64_t rows, int64_t hidden, float eps,
                             int dtype, void* stream);
@@ -227,7 +243,8 @@ int tgis_rope_kv_write_prefill(void* qkv, int64_t ld_qkv, const void* cos, const
 int tgis_attn_num_splits(int64_t B, int Hkv, int H, int64_t max_q_len, int64_t max_ctx);
 int64_t tgis_attn_workspace_bytes(int64_t total_q_tokens, int H, int Hkv, int D, int num_splits);
 /* Causal softmax(q k^T * scale) v over the paged cache.
- *   q: [total_q, H, D] with token stride ld_q (elements); out: [total_q, H*D] contiguous.
+ *   q: [total_q, H, D] with token stride ld_q (elements); out: [total_q, H*D] contiguous (ld_out = 0 or
+ *   H*D), or — decode, B <= 32 — in fragment order for the o_proj GEMM (ld_out = TGIS_LD_FRAGMENTS).
  *   cu_seqlens_q [B+1] int32: q token offsets per sequence (decode: arange).
  *   ctx_lens [B] int32: tokens of each sequence present in the cache INCLUDING the q tokens.
  *   block_tables [B, max_pages] int32: page ids.  q token i of sequence b sits at position
@@ -235,7 +252,7 @@ int64_t tgis_attn_workspace_bytes(int64_t total_q_tokens, int H, int Hkv, int D,
  *   max_q_len / max_ctx are launch-shape bounds (host ints). */
 int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, const void* v_pool,
                     const int32_t* block_tables, int64_t max_pages, const int32_t* ctx_lens,
-                    const int32_t* cu_seqlens_q, void* out, int64_t B, int H, int Hkv, int D,
+                    const int32_t* cu_seqlens_q, void* out, int64_t ld_out, int64_t B, int H, int Hkv, int D,
                     int64_t max_q_len, int64_t max_ctx, float scale, int dtype, int num_splits,
                     void* workspace, int64_t workspace_bytes, void* stream);
 

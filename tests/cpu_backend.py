@@ -73,7 +73,8 @@ def _dense_gemm(x, w, ws, bias=None, out_f32=False, act=0, out=None):
     return y if out_f32 else y.to(w.dtype)
 
 
-def _rmsnorm(x, residual, weight, eps, y=None, res_out=None):
+def _rmsnorm(x, residual, weight, eps, y=None, res_out=None, frag=False):
+    assert not frag  # gptq_fragments_ok is False on this backend
     yy, res = ops_ref.rmsnorm_residual(x, residual, weight, eps)
     return yy.to(x.dtype), (res.to(x.dtype) if residual is not None else x)
 
@@ -160,6 +161,7 @@ def install(monkeypatch):
         act_mul=lambda gu, I, out=None: ops_ref.silu_mul(gu, I).to(gu.dtype),
         gptq_gemm_partial=lambda x, w, bias=None, act=0: _gptq_gemm(x, w, None, bias=bias, act=act),
         gptq_rope_ok=lambda M, w, D: 1 <= M <= 64 and w.perm is None,
+        gptq_fragments_ok=lambda M, w, act=0: False,  # fragment order is a device layout: the CPU stand-ins stay row-major
         rope_gemm_ok=lambda M, w, D: 1 <= M <= 64 and getattr(w, "perm", None) is None,
         dense_gemm_rope=lambda x, w, bias, cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, out=None: _rope_kv_write(
             _dense_gemm(x, w, None, bias=bias), cos, sin, positions, slots, k_pool, v_pool, H, Hkv, D, D),

@@ -328,7 +328,8 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
             V8 ov;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(acc[e] * inv);
-            st16(reinterpret_cast<T*>(a.out) + (tokidx * a.H + headj) * D + dc * 8, ov);
+            st16(reinterpret_cast<T*>(a.out) + (a.out_frag ? xf_off(tokidx, (int64_t)headj * D + dc * 8, (int64_t)a.H * D)
+                                                           : (tokidx * a.H + headj) * D + dc * 8), ov);
         } else if (a.counters) {
             // fused combine: the record leaves as 16-byte write-through stores (no other block's record shares a
             // 128-byte line with it: 16 columns x NS x 16 bytes per (group, chunk))
@@ -441,7 +442,8 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
             for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(acc[it][e] * inv);
             const int64_t tokidx = q0 + t0 + tqj;
             const int headj = hk * a.G + (hc0 + ch) * 16 + gj;
-            st16(reinterpret_cast<T*>(a.out) + (tokidx * a.H + headj) * D + dcs[it] * 8, ov);
+            st16(reinterpret_cast<T*>(a.out) + (a.out_frag ? xf_off(tokidx, (int64_t)headj * D + dcs[it] * 8, (int64_t)a.H * D)
+                                                           : (tokidx * a.H + headj) * D + dcs[it] * 8), ov);
         }
     }
 }
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
 template <typename T, int D>
 __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restrict__ ws_o,
                                                           const float* __restrict__ ws_ml, T* __restrict__ out,
-                                                          int NS) {
+                                                          int NS, int H, int out_frag) {
     const int64_t th = blockIdx.x;  // tok*H + head
     const int lane = threadIdx.x;
     float mstar = NEG_BIG;
@@ -465,7 +467,10 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restric
     }
     const float inv = l > 0.f ? 1.f / l : 0.f;
 #pragma unroll
-    for (int i = 0; i < D / 64; ++i) out[th * D + i * 64 + lane] = from_f32<T>(acc[i] * inv);
+    for (int i = 0; i < D / 64; ++i) {
+        const int64_t o = out_frag ? xf_off(th / H, (th % H) * D + i * 64 + lane, (int64_t)H * D) : th * D + i * 64 + lane;
+        out[o] = from_f32<T>(acc[i] * inv);
+    }
 }
 
 static int next_pow2(int v) {
@@ -545,7 +550,7 @@ static int launch_attn(const AttnArgs& a, dim3 grid, int64_t total_q, hipStream_
     TGIS_CHECK_LAUNCH();
     if (a.NS > 1 && !a.counters) {
         hipLaunchKernelGGL((attn_combine_kernel<T, D>), dim3((unsigned)(total_q * a.H)), dim3(64), 0, st, a.ws_o,
-                           a.ws_ml, (T*)a.out, a.NS);
+                           a.ws_ml, (T*)a.out, a.NS, a.H, a.out_frag);
         TGIS_CHECK_LAUNCH();
     }
     return TGIS_OK;
@@ -665,7 +670,7 @@ struct FusedRope {  // the rotary + cache-write prologue of tgis_attn_decode_rop
 
 static int attn_paged_impl(const void* q, int64_t ld_q, const void* k_pool, const void* v_pool,
                            const int32_t* block_tables, int64_t max_pages, const int32_t* ctx_lens,
-                           const int32_t* cu_seqlens_q, void* out, int64_t B, int H, int Hkv, int D,
+                           const int32_t* cu_seqlens_q, void* out, int64_t ld_out, int64_t B, int H, int Hkv, int D,
                            int64_t max_q_len, int64_t max_ctx, float scale, int dtype, int num_splits,
                            void* workspace, int64_t workspace_bytes, void* stream, const FusedRope* fr) {
     TGIS_CHECK_ARG((q || (fr && fr->slabs)) && k_pool && v_pool && block_tables && ctx_lens && cu_seqlens_q && out,
@@ -676,6 +681,10 @@ static int attn_paged_impl(const void* q, int64_t ld_q, const void* k_pool, cons
     TGIS_CHECK_ARG(ld_q % 8 == 0 && ((uintptr_t)q % 16) == 0, "tgis_attn_paged: q must be 16-byte aligned");
     TGIS_CHECK_ARG(max_q_len > 0 && max_pages > 0 && num_splits >= 1, "tgis_attn_paged: bad launch bounds");
     TGIS_CHECK_ARG(num_splits == 1 || max_q_len == 1, "tgis_attn_paged: key splits are for decode (max_q_len == 1)");
+    TGIS_CHECK_ARG(ld_out == 0 || ld_out == (int64_t)H * D ||
+                       (ld_out == TGIS_LD_FRAGMENTS && max_q_len == 1 && B <= 32 && ((int64_t)H * D) % 64 == 0),
+                   "tgis_attn_paged: out is [tokens, H * D] contiguous (ld_out = 0 or H * D), or — decode, <= 32 sequences — in "
+                   "fragment order (ld_out = TGIS_LD_FRAGMENTS)");
     (void)max_ctx;
     if (B == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -690,6 +699,7 @@ static int attn_paged_impl(const void* q, int64_t ld_q, const void* k_pool, cons
     a.ctx_lens = ctx_lens;
     a.cu_q = cu_seqlens_q;
     a.out = out;
+    a.out_frag = ld_out == TGIS_LD_FRAGMENTS;
     a.H = H;
     a.Hkv = Hkv;
     a.G = g.G;
@@ -763,10 +773,10 @@ static int attn_paged_impl(const void* q, int64_t ld_q, const void* k_pool, cons
 
 extern "C" int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, const void* v_pool,
                                const int32_t* block_tables, int64_t max_pages, const int32_t* ctx_lens,
-                               const int32_t* cu_seqlens_q, void* out, int64_t B, int H, int Hkv, int D,
+                               const int32_t* cu_seqlens_q, void* out, int64_t ld_out, int64_t B, int H, int Hkv, int D,
                                int64_t max_q_len, int64_t max_ctx, float scale, int dtype, int num_splits,
                                void* workspace, int64_t workspace_bytes, void* stream) {
-    return attn_paged_impl(q, ld_q, k_pool, v_pool, block_tables, max_pages, ctx_lens, cu_seqlens_q, out, B, H, Hkv, D,
+    return attn_paged_impl(q, ld_q, k_pool, v_pool, block_tables, max_pages, ctx_lens, cu_seqlens_q, out, ld_out, B, H, Hkv, D,
                            max_q_len, max_ctx, scale, dtype, num_splits, workspace, workspace_bytes, stream, nullptr);
 }
 
@@ -788,7 +798,7 @@ extern "C" int tgis_attn_decode_rope(const void* qkv, int64_t ld_qkv, const floa
                    "tgis_attn_decode_rope: needs a slab row stride >= (H + 2 Hkv) D");
     const FusedRope fr{slabs, num_slabs, slab_ld, slabs ? bias : nullptr, cos, sin, positions, slots, rot_dim};
     return attn_paged_impl(slabs ? nullptr : qkv, slabs ? 8 : ld_qkv, k_pool, v_pool, block_tables, max_pages, ctx_lens,
-                           cu_seqlens_q, out, B, H, Hkv, D, 1, max_ctx, scale, dtype, num_splits, workspace,
+                           cu_seqlens_q, out, 0, B, H, Hkv, D, 1, max_ctx, scale, dtype, num_splits, workspace,
                            workspace_bytes, stream, &fr);
 }
 #endif  // TGIS_EXPERIMENTS

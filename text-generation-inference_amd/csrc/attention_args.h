@@ -12,6 +12,7 @@ struct AttnArgs {
     const int32_t* ctx_lens;
     const int32_t* cu_q;
     void* out;
+    int out_frag;  // 1: out is [<= 32 tokens, H * D] in 32-row fragment order (xf_off in common.h), else row-major
     int H, Hkv, G, Gc, Gp, TQ, HC, NS;
     int HCB;  // decode kernel: blocks per kv head along the 16-head chunks (HC / chunks per block)
     float scale_log2;

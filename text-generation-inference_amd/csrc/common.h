@@ -132,6 +132,14 @@ __device__ __forceinline__ void sum_slabs8(const float* sp, int64_t stride, int 
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Element (row m, column k) of a [rows, K] activation stored in 32-row MFMA-FRAGMENT ORDER (TGIS_LD_FRAGMENTS in
+// include/tgis_hip.h; K % 64 == 0): [row block m / 32][k64-step k / 64][i = k / 8 % 4][lane = 32 (k / 32 % 2) + m % 32][k % 8].
+// One k64-step of a row block is four contiguous KiB, each the A operand of one v_mfma_f32_32x32x16 (lane l holds row l % 32,
+// k-slots 8 (l / 32) ..+8) in the k order of the prepared weight images; 8 consecutive columns stay 16 contiguous bytes.
+__host__ __device__ __forceinline__ int64_t xf_off(int64_t m, int64_t k, int64_t K) {
+    return (m >> 5) * 32 * K + ((((k >> 6) << 2) + ((k >> 3) & 3)) * 64 + ((k >> 5) & 1) * 32 + (m & 31)) * 8 + (k & 7);
+}
+
 // GELU on an fp32 value (exact erf form, or the tanh approximation): ONE function for tgis_gelu and for the GEMM epilogues
 // that apply it to their rounded output.  Not inlined: inside a caller the compiler contracts the expression (and the
 // library's erf / tanh polynomials) with whatever surrounds it, and the two forms then differ in the last bit.

@@ -19,6 +19,7 @@
 #include "common.h"
 #include <type_traits>
 #include "gptq_gemm_body.h"
+#include "gptq_wide_body.h"
 
 namespace {
 
@@ -103,6 +104,14 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
     gptq::WeightRing<4> ring;
     gptq::gptq_gemm_unit<TN, WK, ACT, GROUP64, PERM, MR, false, 4, gptq::UNIT_FULL, NORMP>(a, blockIdx.x, blockIdx.y,
                                                                                            blockIdx.z, smem, 0, ring);
+}
+
+// Decode batches of up to 32 rows whose activation is in fragment order (gptq_wide_body.h).  8 waves; CT = 4 holds 2 waves
+// per SIMD (one block per CU), CT = 2 / 3 leave room for more.
+template <int CT, int ACT, bool OUTF>
+__global__ __launch_bounds__(64 * gptq::WIDE_WK) void gptq_wide_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gptq::gptq_wide_unit<CT, ACT, OUTF>(a, smem);
 }
 
 // ---- "tall" kernel: 64 < M (decode batches beyond 32 rows, add-on prefills of up to a few thousand tokens) --------
@@ -595,6 +604,7 @@ extern "C" int64_t tgis_gptq_gemm_fused_rows(int64_t K, int64_t groups, int act_
 extern "C" int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N) {
     GemmPlan pl = plan_gemm(K, N, 0, M);
     int64_t need = 4096 + slab_bytes(M, N, pl.S);
+    if (M <= 32 && K % 64 == 0) need = std::max(need, 4096 + slab_bytes(M, N, gptq::plan_wide(K, N, 0).S));
     if (M >= tall_min_m() && K % 64 == 0) need = std::max(need, 4096 + tall_slab_bytes(M, N, plan_tall(M, K, N, 0).S));
     return need;
 }
@@ -641,6 +651,19 @@ struct RopeEpi {
     f16 *kpool, *vpool;
     int H, Hkv, D;
 };
+
+template <int CT, int ACT, bool OUTF>
+static int launch_wide_one(dim3 grid, hipStream_t st, const GemmArgs& a) {
+    constexpr size_t lds = (size_t)gptq::WIDE_WK * CT * 4096;
+    static bool attr_done = false;
+    if (!attr_done) {
+        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_wide_kernel<CT, ACT, OUTF>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gptq_wide_kernel<CT, ACT, OUTF>), grid, dim3(64 * gptq::WIDE_WK), lds, st, a);
+    return TGIS_OK;
+}
 
 static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const void* bias, const int32_t* perm,
                        void* out, int64_t ldo, int64_t M, int64_t K, int64_t N, int64_t groups, int act, float* slabs,
@@ -692,6 +715,31 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
         for (a.spg_shift = 0; (1 << a.spg_shift) < spg; ++a.spg_shift) {}
     a.norm = gsync::NormPhase{};
     a.bar = nullptr;
+    if (ldx == TGIS_LD_FRAGMENTS) {
+        // activation in fragment order: the kernel of gptq_wide_body.h; `pl` carries its plan as TN = CT, S (callers use
+        // wide_plan_as_gemm_plan); checked by the caller: wide_serves(), act in {0, 2, 3}, no permutation
+        const bool outf = ldo == TGIS_LD_FRAGMENTS;
+        dim3 wgrid((unsigned)cdiv64(p.NT, pl.TN), (unsigned)pl.S);
+#define TGIS_WIDE(CT)                                                                                   \
+    do {                                                                                                \
+        int rc_ = act == 3   ? launch_wide_one<CT, 3, false>(wgrid, st, a)                              \
+                  : act == 2 ? (outf ? launch_wide_one<CT, 2, true>(wgrid, st, a)                       \
+                                     : launch_wide_one<CT, 2, false>(wgrid, st, a))                     \
+                             : launch_wide_one<CT, 0, false>(wgrid, st, a);                             \
+        if (rc_ != TGIS_OK) return rc_;                                                                 \
+    } while (0)
+        if (pl.TN == 4) TGIS_WIDE(4); else if (pl.TN == 3) TGIS_WIDE(3); else TGIS_WIDE(2);
+#undef TGIS_WIDE
+        TGIS_CHECK_LAUNCH();
+        if (!partial && pl.S > 1) {
+            const int NP = (int)p.NT * 32;
+            dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 4), 256), 1);
+            hipLaunchKernelGGL(splitk_reduce_f16_kernel, rgrid, dim3(256), 0, st, a.slabs, a.bias, a.out, a.ldo, a.M, a.N,
+                               NP, a.S);
+            TGIS_CHECK_LAUNCH();
+        }
+        return TGIS_OK;
+    }
     dim3 grid((unsigned)cdiv64(p.NT, pl.TN), (unsigned)pl.S, (unsigned)mslabs);
     const size_t lds = (size_t)pl.WK * 2 * 32 * pl.MR * RS * sizeof(f16) + 64;  // x buffers + arrival counters
     if (norm) {  // checked by the caller: act 2 / 3, group64, no permutation, <= 32 rows, S == 1, rows <= grid.x <= CUs
@@ -764,8 +812,20 @@ static int check_gemm_args(const void* x, int64_t ldx, const void* prepared, int
     TGIS_CHECK_ARG(groups > 0 && K % groups == 0, "tgis_gptq_gemm: K %% groups != 0");
     TGIS_CHECK_ARG(act == 0 || act == 1 || act == 2, "tgis_gptq_gemm: act must be 0, 1 or 2");
     TGIS_CHECK_ARG(act != 2 || N % 32 == 0, "tgis_gptq_gemm: act=2 needs N/2 to be a multiple of 16");
+    if (ldx == TGIS_LD_FRAGMENTS) {
+        TGIS_CHECK_ARG(((uintptr_t)x % 16) == 0 && gptq::wide_serves(M, K, N, groups, false) && act != 1,
+                       "tgis_gptq_gemm: an activation in fragment order needs 1 <= M <= 32, K %% 64 == 0, groups of 64 * 2^n "
+                       "rows and act 0 or 2 (M=%ld K=%ld N=%ld groups=%ld act=%d)", (long)M, (long)K, (long)N, (long)groups, act);
+        return TGIS_OK;
+    }
     TGIS_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, "tgis_gptq_gemm: x must be 16-byte aligned rows");
     return TGIS_OK;
+}
+
+// the fragment-order kernel's plan in the GemmPlan that launch_gptq takes (TN = column tiles per wave, S = k splits)
+static GemmPlan wide_plan_as_gemm_plan(int64_t K, int64_t N, int act) {
+    const gptq::WidePlan w = gptq::plan_wide(K, N, act);
+    return {0, w.S, gptq::WIDE_WK, w.CT, 1};
 }
 
 extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepared, const void* bias,
@@ -777,6 +837,19 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
     TGIS_CHECK_ARG(out, "tgis_gptq_gemm_f16: null out");
     if (M == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (ldx == TGIS_LD_FRAGMENTS) {
+        TGIS_CHECK_ARG(!perm, "tgis_gptq_gemm_f16: act-order matrices take a row-major activation");
+        TGIS_CHECK_ARG(ldo != TGIS_LD_FRAGMENTS || (act == 2 && (N / 2) % 64 == 0),
+                       "tgis_gptq_gemm_f16: only the act = 2 output (N / 2 a multiple of 64) can leave in fragment order");
+        const GemmPlan wp = wide_plan_as_gemm_plan(K, N, act);
+        const int64_t need_w = 4096 + slab_bytes(M, N, wp.S);
+        TGIS_CHECK_ARG(workspace && workspace_bytes >= need_w, "tgis_gptq_gemm_f16: workspace too small (%ld < %ld)",
+                       (long)workspace_bytes, (long)need_w);
+        TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
+        return launch_gptq(x, ldx, prepared, bias, nullptr, out, ldo, M, K, N, groups, act,
+                           (float*)((uint8_t*)workspace + 4096), 0, wp, st);
+    }
+    TGIS_CHECK_ARG(ldo != TGIS_LD_FRAGMENTS, "tgis_gptq_gemm_f16: a fragment-order output needs a fragment-order activation");
     if (tall_ok(M, K, groups, perm, act)) {
         const TallPlan tp = plan_tall(M, K, N, act);
         const int64_t need_t = 4096 + (tp.S > 1 ? tall_slab_bytes(M, N, tp.S) : 0);
@@ -851,6 +924,7 @@ extern "C" int tgis_gptq_gemm_rope_f16(const void* x, int64_t ldx, const void* p
     TGIS_CHECK_ARG(H >= 1 && Hkv >= 1 && (H + 2 * Hkv) * D == N && ldq >= H * D,
                    "tgis_gptq_gemm_rope_f16: N must be (H + 2 Hkv) * D and q rows must hold H * D elements");
     GemmPlan pl = plan_gemm(K, N, 2, M);  // as the SiLU epilogue: the whole k range in one block (S == 1)
+    if (ldx == TGIS_LD_FRAGMENTS) pl = wide_plan_as_gemm_plan(K, N, 3);
     RopeEpi rope{positions, slots, (const f16*)cos, (const f16*)sin, (f16*)k_pool, (f16*)v_pool, (int)H, (int)Hkv, (int)D};
     hipStream_t st = (hipStream_t)stream;
     TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
@@ -917,6 +991,7 @@ int norm_phase_of(const tgis_norm_in* n, int64_t M, int64_t K, gsync::NormPhase*
     TGIS_CHECK_ARG(n && (n->slabs || n->x) && n->weight && n->y, "tgis_gptq_norm_gemm: null norm tensor");
     TGIS_CHECK_ARG(!n->slabs || (n->num_slabs >= 1 && n->slab_ld >= K && n->slab_ld % 4 == 0),
                    "tgis_gptq_norm_gemm: partial input needs a slab row stride >= hidden");
+    p->y_frag = 0;
     p->slabs = n->slabs;
     p->S = n->num_slabs;
     p->slab_ld = n->slab_ld;
@@ -998,8 +1073,22 @@ extern "C" int tgis_gptq_norm_qkv_rope_f16(const tgis_norm_in* norm, const void*
 extern "C" int64_t tgis_gptq_gemm_partial_bytes(int64_t M, int64_t K, int64_t N) {
     GemmPlan pl = plan_gemm(K, N, 0, M);
     int64_t need = cdiv64(std::max<int64_t>(M, 1), 64) * 2 * pl.S * 32 * cdiv64(N, 32) * 32 * 4;
+    if (M <= 32 && K % 64 == 0)  // the fragment-order kernel's plan may split further
+        need = std::max<int64_t>(need, (int64_t)2 * gptq::plan_wide(K, N, 0).S * 32 * cdiv64(N, 32) * 32 * 4);
     if (M >= tall_min_m() && K % 64 == 0) need = std::max(need, tall_slab_bytes(M, N, plan_tall(M, K, N, 0).S));
     return need;
+}
+
+// Is an activation in fragment order (TGIS_LD_FRAGMENTS) served for this GEMM, and expected to beat the row-major launch?
+// act 2 / 3 keep the whole k range in a block: only while that still covers the chip (>= 128 blocks, as tgis_gptq_rope_ok).
+extern "C" int tgis_gptq_fragments_ok(int64_t M, int64_t K, int64_t N, int64_t groups, int act_order, int act) {
+    if (groups <= 0 || K <= 0 || N <= 0 || !gptq::wide_serves(M, K, N, groups, act_order != 0)) return 0;
+    if (act != 0 && act != 2 && act != 3) return 0;
+    static const bool off = getenv("TGIS_GPTQ_FRAGMENTS") && atoi(getenv("TGIS_GPTQ_FRAGMENTS")) == 0;
+    if (off) return 0;
+    static const int64_t min_blocks = getenv("TGIS_ROPE_MIN_BLOCKS") ? atoll(getenv("TGIS_ROPE_MIN_BLOCKS")) : 128;
+    if ((act == 2 || act == 3) && gptq::wide_blocks(K, N, act) < min_blocks) return 0;
+    return 1;
 }
 
 extern "C" int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void* prepared, const int32_t* perm,
@@ -1019,6 +1108,10 @@ extern "C" int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void
         return launch_tall(x, ldx, prepared, nullptr, nullptr, 0, M, K, N, groups, act, slabs, 1, tp, (hipStream_t)stream);
     }
     GemmPlan pl = plan_gemm(K, N, 0, M);
+    if (ldx == TGIS_LD_FRAGMENTS) {
+        TGIS_CHECK_ARG(!perm && act == 0, "tgis_gptq_gemm_f16_partial: fragment-order activations: act 0, no act-order");
+        pl = wide_plan_as_gemm_plan(K, N, 0);
+    }
     TGIS_CHECK_ARG(slabs && slabs_bytes >= tgis_gptq_gemm_partial_bytes(M, K, N),
                    "tgis_gptq_gemm_f16_partial: slab buffer too small");
     hipStream_t st = (hipStream_t)stream;

@@ -1,0 +1,292 @@
+// The int4 GPTQ GEMM for decode batches of up to 32 rows whose activation arrives in MFMA-fragment order (round 4).
+//
+// Replaces exllamav2_kernels.gemm_half_q_half (utils/gptq/exllamav2.py:139-144) on the decode step, like the streaming
+// kernel of gptq_gemm_body.h, on the same prepared image.  What is different, and why (tools/floor/wide.hip measured every
+// step on the cfg3 shapes, profiles/r04_wide_*.log):
+//   * the activation is not staged through LDS chunk by chunk.  Its producer (add + RMSNorm, the attention epilogue, the
+//     SiLU * up epilogue of this kernel) writes it in FRAGMENT ORDER — xf[k64-step][i][lane][8 halves], lane = 32 (k / 32 % 2)
+//     + row, i = k / 8 % 4 (xf_off in common.h) — so the A operand of the four MFMAs of a k64-step is four contiguous
+//     one-KiB loads straight into registers, and a wave needs nobody else's data until the very end: no chunk hand-offs,
+//     no arrival counters, no barrier in front of the first MFMA.  Row-major x read the same way costs 1.4 - 2.6 us per
+//     launch (32 rows at a stride of 8 KiB: 32 cache lines per load instruction, all in one L1 set);
+//   * a wave owns CT (2 - 4) 32-column tiles, not one: every A fragment feeds CT MFMAs;
+//   * the 8 waves of a block split the block's k range; their fp32 sums meet once, in LDS laid out [k-part][tile][register]
+//     [lane] — every access 64 consecutive words (the [lane][16] layout of the streaming kernel is a 16-way bank conflict:
+//     2.3 us of a 10 us launch) — and every wave finishes two of the sixteen accumulator rows of each tile (fixed order);
+//   * two k64-steps of weights + scales + activation in flight per wave, refilled in place; the last steps are taken by
+//     wave-uniform branches, so no wave dequantises padding.
+// cfg3 shapes, 32 rows, us per launch (streaming kernel -> this one): qkv + rope epilogue 16.9 -> 12.x, o 6.0 -> 5.3,
+// gate_up + SiLU 16.8 -> 14.x, down 10.5 -> 9.2.
+#pragma once
+#include "gptq_gemm_body.h"
+
+namespace gptq {
+
+constexpr int WIDE_WK = 8;      // k-parts (waves) per block
+constexpr int WIDE_DEPTH = 2;   // k64-steps in flight per wave
+
+struct WidePlan {
+    int CT, S;  // column tiles per wave (= per block), global k splits
+};
+
+// Does the fragment-order kernel serve this GEMM at all?  (<= 32 rows, whole k64-steps, one {scale, zero} per k64-step and
+// column, no act-order permutation.)
+static inline bool wide_serves(int64_t M, int64_t K, int64_t N, int64_t groups, bool act_order) {
+    if (M < 1 || M > 32 || act_order || K % 64 || N % 32 || groups < 1 || K % groups) return false;
+    const int64_t gs = K / groups;
+    if (groups == 1) return true;
+    if (gs % 64) return false;
+    const int64_t spg = gs / 64;
+    return (spg & (spg - 1)) == 0;
+}
+
+// One block per CU where the shape allows it: column groups first (a wider group re-uses an A fragment more often), then
+// global k splits (fp32 slabs that the consumer sums) until ~256 blocks; at least one k64-step per wave.
+// act 2 / 3 (SiLU * up, rotary + cache write) finish their outputs in the epilogue: no split.
+static inline WidePlan plan_wide(int64_t K, int64_t N, int act) {
+    if (const char* ov = getenv("TGIS_GPTQ_WIDE_PLAN")) {  // tuning hook: "CT,S"
+        int ct = 0, sp = 0;
+        if (sscanf(ov, "%d,%d", &ct, &sp) == 2 && ct >= 2 && ct <= 4 && sp >= 1 && (sp == 1 || (act != 2 && act != 3)))
+            return {ct, sp};
+    }
+    const int64_t tiles = cdiv64(N, 32), steps = K / 64;
+    int CT = 2;
+    while (CT < 4 && cdiv64(tiles, CT) > 256) ++CT;
+    int64_t S = 1;
+    if (act != 2 && act != 3) {
+        const int64_t cgs = cdiv64(tiles, CT);
+        S = std::max<int64_t>(1, (256 + cgs / 2) / cgs);
+        S = std::min<int64_t>(S, std::max<int64_t>(1, steps / WIDE_WK));
+        while (S > 1 && (S - 1) * cdiv64(steps, S) >= steps) --S;  // no empty last split
+    }
+    return {CT, (int)S};
+}
+static inline int64_t wide_blocks(int64_t K, int64_t N, int act) {
+    const WidePlan p = plan_wide(K, N, act);
+    return cdiv64(cdiv64(N, 32), p.CT) * p.S;
+}
+
+// OUTF: the act = 2 output (the operand of the down projection) leaves in fragment order as well.
+template <int CT, int ACT, bool OUTF>
+__device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char* smem) {
+    constexpr int WK = WIDE_WK, DEPTH = WIDE_DEPTH, NR = 16 / WK;
+    const int lane = threadIdx.x & 63;
+    const int wk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cg = blockIdx.x, split = blockIdx.y;
+    const int steps = a.K >> 6;
+    const int sp_len = (steps + a.S - 1) / a.S;
+    const int sb = split * sp_len, se = min(steps, sb + sp_len);
+    const int len = max(se - sb, 0);
+    const int s0 = sb + (len * wk) / WK, s1 = sb + (len * (wk + 1)) / WK;  // this wave's k64-steps (may be empty)
+    const int mrows = a.M;  // 1..32
+
+    const char* wt[CT];
+    const char* st[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int nt = min(cg * CT + t, a.NT - 1);  // a tile past the matrix re-reads the last one and is never stored
+        wt[t] = reinterpret_cast<const char*>(a.prep) + (int64_t)nt * a.KS * 1024;
+        st[t] = reinterpret_cast<const char*>(a.prep + a.offB) + (int64_t)nt * a.G * 128;
+    }
+    const uint32_t woff = lane * 16, szoff = (lane & 31) * 4;
+    const int sclamp = max(s1 - 1, s0);  // loads past the wave's steps re-read its last one (a cache hit), never consumed
+    const char* xb = reinterpret_cast<const char*>(a.x);
+
+    u32x4 wq[DEPTH][CT];
+    uint32_t sz[DEPTH][CT];
+    f16x8 xa[DEPTH][4];
+    auto load_step = [&](int d, int step) {
+        const int sc = min(step, sclamp);
+        const int g = min(sc >> a.spg_shift, a.G - 1);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const char* p = st[t] + (int64_t)g * 128;
+            PIN_SGPR(p);
+            sz[d][t] = *(const GLOBAL_AS uint32_t*)(p + szoff);
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const char* p = wt[t] + (int64_t)sc * 1024;
+            PIN_SGPR(p);
+            wq[d][t] = __builtin_nontemporal_load((const GLOBAL_AS u32x4*)(p + woff));
+        }
+        const char* p = xb + (int64_t)sc * 4096;  // fragment order: four contiguous KiB per k64-step
+        PIN_SGPR(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xa[d][i] = *(const GLOBAL_AS f16x8*)(p + woff + i * 1024);
+    };
+
+    // ACT 3: cache slot and rotary position of the two rows this wave finishes
+    int32_t rpos[ACT == 3 ? NR : 1], rslot[ACT == 3 ? NR : 1];
+    if (ACT == 3) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int r = wk * NR + j;
+            const int m = min((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), mrows - 1);
+            rpos[j] = a.positions[m];
+            rslot[j] = a.slots[m];
+        }
+    }
+
+    uint32_t EXr = 0x64006400u, M0r = 0x000F000Fu, M1r = 0x00F000F0u;
+    asm volatile("" : "+v"(EXr));
+    asm volatile("" : "+s"(M0r), "+s"(M1r));
+    f32x16 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_step(d, s0 + d);
+
+    auto consume = [&](int d) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const f16x2 szh = __builtin_bit_cast(f16x2, sz[d][t]);
+            const f16 zc1 = szh[1];
+            const f16 zd1 = (f16)960.f - zc1;  // -(64 + z + 1), exact
+            const f16x2 zc = {zc1, zc1}, zd = {zd1, zd1}, sc = {szh[0], szh[0]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f16x8 b = dequant8(wq[d][t][i], zc, zd, sc, EXr, M0r, M1r);
+                acc[t] = mfma32(xa[d][i], b, acc[t]);
+            }
+        }
+    };
+
+    int s = s0;
+    for (; s + DEPTH < s1; s += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            consume(d);
+            __builtin_amdgcn_sched_barrier(0);
+            load_step(d, s + d + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the last group: only the steps that exist (wave-uniform branches; nothing is requested any more)
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (s + d < s1) consume(d);
+
+    // ACT 3: the finishing rows' cos / sin entries are requested before the exchange (their positions came in at entry)
+    f16 rcos[ACT == 3 ? CT : 1][ACT == 3 ? NR : 1], rsin[ACT == 3 ? CT : 1][ACT == 3 ? NR : 1];
+    if (ACT == 3) {
+        const int per = a.rD >> 5;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int nt = min(cg * CT + t, a.NT - 1);
+            const int tt = nt - (nt / per) * per;
+            const int dr = 16 * tt + (lane & 15);
+            const bool roth = nt / per < a.rH + a.rHkv;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                rcos[t][j] = roth ? a.cosb[(int64_t)rpos[j] * (a.rD >> 1) + dr] : (f16)1.f;
+                rsin[t][j] = roth ? a.sinb[(int64_t)rpos[j] * (a.rD >> 1) + dr] : (f16)0.f;
+            }
+        }
+    }
+
+    // ---- k-part sum through LDS: [k-part][tile][register][lane], then wave wk sums registers [wk NR, (wk + 1) NR) ----
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        float* dst = red + ((wk * CT + t) << 10) + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r << 6] = acc[t][r];
+    }
+    __syncthreads();
+    float fin[CT][NR];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+#pragma unroll
+        for (int k2 = 0; k2 < WK; ++k2) {
+            const float* src = red + ((k2 * CT + t) << 10) + ((wk * NR) << 6) + lane;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) fin[t][j] = k2 == 0 ? src[j << 6] : fin[t][j] + src[j << 6];
+        }
+    }
+
+    const int c = lane & 31;
+    auto row_of = [&](int j) {
+        const int r = wk * NR + j;
+        return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    };
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int nt = cg * CT + t;
+        if (nt >= a.NT) break;
+        if (ACT == 3) {
+            // rope image: see gptq_gemm_body.h (the same epilogue on the same image)
+            const int per = a.rD >> 5;
+            const int head = nt / per, tt = nt - head * per;
+            const bool roth = head < a.rH + a.rHkv;
+            const int d = roth ? ((c < 16) ? 16 * tt + c : (a.rD >> 1) + 16 * tt + (c - 16)) : 32 * tt + c;
+            const int col = head * a.rD + d;
+            const float bv = a.bias ? (float)a.bias[col] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int m = row_of(j);
+                const float mine = (float)(f16)(fin[t][j] + bv);
+                float o = mine;
+                if (roth) {
+                    const float other = __shfl_xor(mine, 16, 64);
+                    const float cf = (float)rcos[t][j], sf = (float)rsin[t][j];
+                    o = (c < 16) ? mine * cf - other * sf : other * sf + mine * cf;
+                }
+                const f16 oh = (f16)o;
+                if (m < mrows) {
+                    if (head < a.rH) {
+                        a.out[(int64_t)m * a.ldo + col] = oh;
+                    } else {
+                        const int page = rslot[j] >> 5, tok = rslot[j] & 31;
+                        if (roth)
+                            a.kpool[((int64_t)page * a.rHkv + (head - a.rH)) * 32 * a.rD + k_off(tok, d, a.rD)] = oh;
+                        else
+                            a.vpool[((int64_t)page * a.rHkv + (head - a.rH - a.rHkv)) * 32 * a.rD + (int64_t)d * 32 +
+                                    v_col(tok)] = oh;
+                    }
+                }
+            }
+            continue;
+        }
+        const int n = nt * 32 + c;
+        if (ACT == 2) {
+            // interleaved gate / up image: lanes c < 16 hold gate column j2, lanes c + 16 the matching up column
+            const int half = a.N >> 1;
+            const int j2 = nt * 16 + (c & 15);
+            const int nsrc = (c < 16) ? j2 : half + j2;
+            const float bv = (a.bias && j2 < half) ? (float)a.bias[nsrc] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const float mine = (float)(f16)(fin[t][j] + bv);
+                const float other = __shfl_xor(mine, 16, 64);
+                const int m = row_of(j);
+                if (c < 16 && j2 < half && m < mrows) {
+                    const float sl = mine / (1.f + __expf(-mine));
+                    const f16 o = (f16)((float)(f16)sl * other);
+                    if (OUTF)
+                        a.out[xf_off(m, j2, half)] = o;
+                    else
+                        a.out[(int64_t)m * a.ldo + j2] = o;
+                }
+            }
+            continue;
+        }
+        if (a.S == 1 && !a.partial) {
+            const float bv = (a.bias && n < a.N) ? (float)a.bias[n] : 0.f;
+            if (n < a.N) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int m = row_of(j);
+                    if (m < mrows) a.out[(int64_t)m * a.ldo + n] = (f16)(fin[t][j] + bv);
+                }
+            }
+        } else {
+            float* sl = a.slabs + ((int64_t)split * 32) * (a.NT * 32) + n;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) sl[(int64_t)row_of(j) * (a.NT * 32)] = fin[t][j];
+        }
+    }
+}
+
+}  // namespace gptq

@@ -103,6 +103,7 @@ struct NormPhase {
     void* res_out;        // T [rows, hidden]: x (+ residual), the residual stream (may alias nothing the launch reads)
     int rows, hidden;
     float eps;
+    int y_frag;           // 1: y leaves in 32-row fragment order (xf_off in common.h; rows <= 32, hidden % 64 == 0)
 };
 
 // One row by all `nthreads` threads of the workgroup (nthreads a multiple of 64, <= 1024); `sh` = >= 16 floats of LDS that
@@ -187,7 +188,7 @@ __device__ __forceinline__ void norm_row(const NormPhase& p, const int row, floa
             if (SC1)
                 st_sc1(__builtin_bit_cast(u32x4, o), ry, ((int64_t)row * p.hidden + c * 8) * 2);
             else
-                st16(reinterpret_cast<T*>(p.y) + (int64_t)row * p.hidden + c * 8, o);
+                st16(reinterpret_cast<T*>(p.y) + (p.y_frag ? xf_off(row, c * 8, p.hidden) : (int64_t)row * p.hidden + c * 8), o);
         }
     }
 }

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
                                                   const T* __restrict__ weight, const T* __restrict__ bias,
                                                   T* y, T* res_out, int hidden,
                                                   float eps, const float* __restrict__ slabs, int S, int64_t slab_ld,
-                                                  const T* __restrict__ xbias) {
+                                                  const T* __restrict__ xbias, int y_frag) {
     using V8 = typename VecT<T>::x8;
     constexpr int MAXV = MAX_HIDDEN / (NT * 8);
     __shared__ float sh[NT / 64];
@@ -53,6 +53,7 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
         p.rows = gridDim.x;
         p.hidden = hidden;
         p.eps = eps;
+        p.y_frag = y_frag;
         gsync::norm_row<T, MAXV, false>(p, (int)row, sh, NT);
         return;
     }
@@ -151,13 +152,18 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
 template <bool RMS>
 static int launch_norm(const void* x, const void* residual, const void* weight, const void* bias, void* y,
                        void* res_out, int64_t rows, int64_t hidden, float eps, int dtype, void* stream,
-                       const float* slabs = nullptr, int S = 0, int64_t slab_ld = 0, const void* xbias = nullptr) {
+                       const float* slabs = nullptr, int S = 0, int64_t slab_ld = 0, const void* xbias = nullptr,
+                       int64_t ldy = 0) {
     TGIS_CHECK_ARG((x || slabs) && weight && y, "norm: null tensor");
     TGIS_CHECK_ARG(!slabs || (S >= 1 && slab_ld >= hidden && slab_ld % 4 == 0),
                    "norm: partial input needs a slab row stride >= hidden");
     TGIS_CHECK_ARG(hidden > 0 && hidden % 8 == 0 && hidden <= MAX_HIDDEN,
                    "norm: hidden (%ld) must be a multiple of 8 and <= %d", (long)hidden, MAX_HIDDEN);
     TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "norm: bad dtype");
+    const int y_frag = ldy == TGIS_LD_FRAGMENTS;
+    TGIS_CHECK_ARG(ldy == 0 || ldy == hidden || (y_frag && RMS && rows <= 32 && hidden % 64 == 0),
+                   "norm: y is [rows, hidden] contiguous (ldy = 0 or hidden), or — RMSNorm, rows <= 32, hidden %% 64 == 0 — in "
+                   "fragment order (ldy = TGIS_LD_FRAGMENTS)");
     if (rows == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;
     TgisTimedScope timed(TGIS_OP_NORM, st);
@@ -167,11 +173,11 @@ static int launch_norm(const void* x, const void* residual, const void* weight, 
         if (wide)                                                                                                \
             hipLaunchKernelGGL((norm_kernel<T, RMS, P, 512>), dim3((unsigned)rows), dim3(512), 0, st, (const T*)x, \
                                (const T*)residual, (const T*)weight, (const T*)bias, (T*)y, (T*)res_out,         \
-                               (int)hidden, eps, slabs, S, slab_ld, (const T*)xbias);                            \
+                               (int)hidden, eps, slabs, S, slab_ld, (const T*)xbias, y_frag);                    \
         else                                                                                                     \
             hipLaunchKernelGGL((norm_kernel<T, RMS, P, 256>), dim3((unsigned)rows), dim3(256), 0, st, (const T*)x, \
                                (const T*)residual, (const T*)weight, (const T*)bias, (T*)y, (T*)res_out,         \
-                               (int)hidden, eps, slabs, S, slab_ld, (const T*)xbias);                            \
+                               (int)hidden, eps, slabs, S, slab_ld, (const T*)xbias, y_frag);                    \
     } while (0)
     if (dtype == TGIS_F16) {
         if (slabs) TGIS_NORM_LAUNCH(f16, true); else TGIS_NORM_LAUNCH(f16, false);
@@ -185,18 +191,19 @@ static int launch_norm(const void* x, const void* residual, const void* weight, 
 
 }  // namespace
 
-extern "C" int tgis_rmsnorm_residual(const void* x, const void* residual, const void* weight, void* y,
+extern "C" int tgis_rmsnorm_residual(const void* x, const void* residual, const void* weight, void* y, int64_t ldy,
                                      void* res_out, int64_t rows, int64_t hidden, float eps, int dtype,
                                      void* stream) {
-    return launch_norm<true>(x, residual, weight, nullptr, y, res_out, rows, hidden, eps, dtype, stream);
+    return launch_norm<true>(x, residual, weight, nullptr, y, res_out, rows, hidden, eps, dtype, stream, nullptr, 0, 0,
+                             nullptr, ldy);
 }
 
 extern "C" int tgis_rmsnorm_residual_partial(const float* slabs, int num_slabs, int64_t slab_ld, const void* bias,
-                                             const void* residual, const void* weight, void* y, void* res_out,
+                                             const void* residual, const void* weight, void* y, int64_t ldy, void* res_out,
                                              int64_t rows, int64_t hidden, float eps, int dtype, void* stream) {
     TGIS_CHECK_ARG(slabs, "tgis_rmsnorm_residual_partial: null slabs");
     return launch_norm<true>(nullptr, residual, weight, nullptr, y, res_out, rows, hidden, eps, dtype, stream, slabs,
-                             num_slabs, slab_ld, bias);
+                             num_slabs, slab_ld, bias, ldy);
 }
 
 extern "C" int tgis_layernorm_residual_partial(const float* slabs, int num_slabs, int64_t slab_ld, const void* xbias,

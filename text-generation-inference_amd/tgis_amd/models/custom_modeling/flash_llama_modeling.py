@@ -78,14 +78,21 @@ class KVArgs:
 # measured slower than the launches they replace) live in experiments/, not on this path.
 
 
+def frag_rows(linear, rows: int, kv: "KVArgs", act: int = 0) -> bool:
+    """Decode step of <= 32 rows in front of an int4 linear that takes its operand in fragment order (native.FragAct)."""
+    return (kv.max_q_len == 1 and not kv.fresh_prefill and rows <= 32 and hasattr(linear, "wants_fragments")
+            and linear.wants_fragments(rows, act))
+
+
 class LlamaRMSNorm:
     def __init__(self, prefix, weights, eps=1e-6):
         self.weight = weights.get_tensor(f"{prefix}.weight").contiguous()
         self.variance_epsilon = eps
 
-    def forward(self, hidden_states, residual=None):
+    def forward(self, hidden_states, residual=None, frag: bool = False):
         # returns (normed, res) like the reference; res is hidden_states itself when residual is None
-        return native.rmsnorm_residual(hidden_states, residual, self.weight, self.variance_epsilon)
+        # frag: the normed activation leaves in fragment order (native.FragAct) for the int4 GEMM behind it
+        return native.rmsnorm_residual(hidden_states, residual, self.weight, self.variance_epsilon, frag=frag)
 
     __call__ = forward
 
@@ -138,7 +145,8 @@ class FlashLlamaAttention:
         k_pool, v_pool = kv.cache.k_pool(layer_id), kv.cache.v_pool(layer_id)
         lin = self.query_key_value.linear
         rope_w = getattr(lin, "rope_handle", None)
-        if (rope_w is not None and kv.slots is not None and not kv.fresh_prefill and kv.max_q_len == 1
+        if isinstance(hidden_states, native.FragAct) or (
+                rope_w is not None and kv.slots is not None and not kv.fresh_prefill and kv.max_q_len == 1
                 and hidden_states.shape[0] <= 64 and cos.shape[1] * 2 == D
                 and native.rope_gemm_ok(hidden_states.shape[0], rope_w, D)):
             # one launch: GEMM + rotary embedding + cache write (native.gptq_gemm_rope / native.dense_gemm_rope)
@@ -156,8 +164,11 @@ class FlashLlamaAttention:
         H, Hkv, D = self.num_heads, self.num_key_value_heads, self.head_size
         k_pool, v_pool = kv.cache.k_pool(layer_id), kv.cache.v_pool(layer_id)
         T = qkv.shape[0]
-        attn_output = torch.empty((T, H * D), dtype=qkv.dtype, device=qkv.device)
         B = kv.block_tables.shape[0]
+        if frag_rows(self.o_proj.linear, T, kv):  # decode: the o_proj GEMM reads its operand in fragment order
+            attn_output = native.FragAct.empty(T, H * D, qkv.device)
+        else:
+            attn_output = torch.empty((T, H * D), dtype=qkv.dtype, device=qkv.device)
         ws = None
         if kv.num_splits > 1:
             from tgis_amd.utils.layers import workspace
@@ -194,6 +205,10 @@ class LlamaMLP:
 
     def forward(self, hidden_states):
         if self.fused_epilogue:
+            if isinstance(hidden_states, native.FragAct):  # decode: SiLU * up leaves in the layout down_proj reads
+                rows = hidden_states.shape[0]
+                act = self.gate_up_proj(hidden_states, out_frag=self.down_proj.linear.wants_fragments(rows))
+                return self.down_proj(act, partial=True)
             act = self.gate_up_proj(hidden_states)  # [T, I], already silu(gate) * up
             return self.down_proj(act, partial=True)
         gate_up_states = self.gate_up_proj(hidden_states)  # [T, 2, I]
@@ -214,9 +229,16 @@ class FlashLlamaLayer:
                                                      eps=config.rms_norm_eps)
 
     def forward(self, hidden_states, residual, cos, sin, position_ids, cu_seqlens_q, kv: KVArgs):
-        normed_hidden_states, res = self.input_layernorm(hidden_states, residual)
-        attn_output = self.self_attn(normed_hidden_states, cos, sin, position_ids, cu_seqlens_q, self.layer_id, kv)
-        normed_attn_res_output, attn_res = self.post_attention_layernorm(attn_output, res)
+        rows = hidden_states.shape[0]
+        att = self.self_attn
+        # decode steps of <= 32 rows hand the int4 GEMMs their operands in fragment order (native.FragAct): the qkv + rotary
+        # launch when it serves the step, the MLP when the SiLU * up epilogue does
+        qkv_frag = (kv.slots is not None and cos.shape[1] * 2 == att.head_size
+                    and frag_rows(att.query_key_value.linear, rows, kv, act=3))
+        normed_hidden_states, res = self.input_layernorm(hidden_states, residual, frag=qkv_frag)
+        attn_output = att(normed_hidden_states, cos, sin, position_ids, cu_seqlens_q, self.layer_id, kv)
+        mlp_frag = self.mlp.fused_epilogue and frag_rows(self.mlp.gate_up_proj.linear, rows, kv, act=2)
+        normed_attn_res_output, attn_res = self.post_attention_layernorm(attn_output, res, frag=mlp_frag)
         mlp_output = self.mlp(normed_attn_res_output)
         return mlp_output, attn_res
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "tgis_dense_gemm_rope": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_i64,
                                       _c_i64, _c_i64, _c_i64, _c_int, _vp]),
     "tgis_gptq_rope_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_i64]),
+    "tgis_gptq_fragments_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int]),
     "tgis_dense_rope_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64]),
     "tgis_gptq_gemm_rope_f16": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _c_i64,
                                          _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp]),
@@ -61,8 +62,8 @@ SIGNATURES = {
     "tgis_dense_gemm_partial_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
     "tgis_dense_gemm_partial": (_c_int, [_vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _vp, _c_i64,
                                          ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64), _vp]),
-    "tgis_rmsnorm_residual": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f, _c_int, _vp]),
-    "tgis_rmsnorm_residual_partial": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f,
+    "tgis_rmsnorm_residual": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _vp, _c_i64, _c_i64, _c_f, _c_int, _vp]),
+    "tgis_rmsnorm_residual_partial": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _vp, _vp, _c_i64, _vp, _c_i64, _c_i64, _c_f,
                                                _c_int, _vp]),
     "tgis_layernorm_residual": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f, _c_int, _vp]),
     "tgis_layernorm_residual_partial": (_c_int, [_vp, _c_int, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64,
@@ -75,7 +76,7 @@ SIGNATURES = {
                                             _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "tgis_attn_num_splits": (_c_int, [_c_i64, _c_int, _c_int, _c_i64, _c_i64]),
     "tgis_attn_workspace_bytes": (_c_i64, [_c_i64, _c_int, _c_int, _c_int, _c_int]),
-    "tgis_attn_paged": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_int, _c_int,
+    "tgis_attn_paged": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_i64, _c_int, _c_int,
                                  _c_int, _c_i64, _c_i64, _c_f, _c_int, _c_int, _vp, _c_i64, _vp]),
     "tgis_act_mul": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_int, _c_int, _vp]),
     "tgis_gelu": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _vp]),
@@ -195,6 +196,52 @@ class Workspace:
         return self.buf.numel()
 
 
+# ---- activations in MFMA-fragment order (TGIS_LD_FRAGMENTS) ------------------------------------------------------------
+LD_FRAGMENTS = -32
+
+
+class FragAct:
+    """A [M <= 32, K] f16 activation stored in fragment order (include/tgis_hip.h, TGIS_LD_FRAGMENTS): what the decode
+    step's norm / attention / SiLU epilogue hand to the int4 GEMM behind them.  `buf` always holds 32 * K elements."""
+
+    def __init__(self, buf: torch.Tensor, M: int, K: int):
+        assert buf.dtype == torch.float16 and buf.numel() == 32 * K and K % 64 == 0 and 1 <= M <= 32
+        self.buf, self.M, self.K = buf, M, K
+        self.dtype, self.device = buf.dtype, buf.device
+
+    @property
+    def shape(self):
+        return (self.M, self.K)
+
+    @staticmethod
+    def empty(M: int, K: int, device) -> "FragAct":
+        return FragAct(torch.empty(32 * K, dtype=torch.float16, device=device), M, K)
+
+    @staticmethod
+    def from_rows(x: torch.Tensor) -> "FragAct":
+        """Row-major [M, K] -> fragment order (torch ops; tests and cold paths only)."""
+        M, K = x.shape
+        full = torch.zeros((32, K), dtype=x.dtype, device=x.device)
+        full[:M] = x
+        # (m, step, half, i, e) -> [step][i][half][m][e]
+        f = full.view(32, K // 64, 2, 4, 8).permute(1, 3, 2, 0, 4).contiguous().view(-1)
+        return FragAct(f, M, K)
+
+    def to_rows(self) -> torch.Tensor:
+        K = self.K
+        return self.buf.view(K // 64, 4, 2, 32, 8).permute(3, 0, 2, 1, 4).reshape(32, K)[:self.M].contiguous()
+
+
+def gptq_fragments_ok(M: int, w: "GptqWeight", act: int = 0) -> bool:
+    """Should an M-row activation reach this int4 GEMM in fragment order (tgis_gptq_fragments_ok)?  act 3 = the rope image."""
+    key = ("frag_ok", M, act)
+    cache = w.__dict__.setdefault("_frag_ok", {})
+    got = cache.get(key)
+    if got is None:
+        got = cache[key] = bool(load_library().tgis_gptq_fragments_ok(M, w.K, w.N, w.groups, int(w.perm is not None), act))
+    return got
+
+
 # ---- GPTQ ------------------------------------------------------------------------------------------
 class GptqWeight:
     """Prepared (repacked) GPTQ matrix; owner of the device image. Mirrors the q_handle of
@@ -248,13 +295,31 @@ class GptqWeight:
         return load_library().tgis_gptq_gemm_fused_rows(self.K, self.groups, int(self.perm is not None), act)
 
 
-def gptq_gemm(x: torch.Tensor, w: GptqWeight, ws: Workspace, bias=None, act: int = 0, out=None) -> torch.Tensor:
+def gptq_gemm(x, w: GptqWeight, ws: Workspace, bias=None, act: int = 0, out=None, out_frag: bool = False):
     """act 0: out[M,N] = x @ dequant(W) (+bias); act 1: x is [M,2K], silu(x[:, :K]) * x[:, K:] is the operand;
-    act 2 (weight prepared with gate_up=True): out[M,N/2] = silu(gate) * up."""
+    act 2 (weight prepared with gate_up=True): out[M,N/2] = silu(gate) * up.
+    x may be a FragAct (decode, M <= 32); with act 2 the result may then leave as a FragAct too (out_frag)."""
+    assert act != 2 or w.flags & 1, "act=2 needs a weight prepared with gate_up=True"
+    if isinstance(x, FragAct):
+        assert x.K == w.K and act in (0, 2) and w.perm is None
+        M = x.M
+        if out_frag:
+            assert act == 2 and out is None
+            res = FragAct.empty(M, w.N // 2, x.device)
+            optr, ldo = _ptr(res.buf), LD_FRAGMENTS
+        else:
+            res = out if out is not None else torch.empty((M, w.N // 2 if act == 2 else w.N), dtype=torch.float16,
+                                                          device=x.device)
+            optr, ldo = _ptr(res), res.stride(0)
+        ws.ensure(w.workspace_bytes(M))
+        _check(
+            load_library().tgis_gptq_gemm_f16(_ptr(x.buf), LD_FRAGMENTS, _ptr(w.image), _ptr(bias), None, optr, ldo, M, w.K,
+                                              w.N, w.groups, act, ws.ptr, ws.nbytes, _stream()), "tgis_gptq_gemm_f16")
+        return res
+    assert not out_frag, "a fragment-order output needs a fragment-order activation"
     assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1
     M = x.shape[0]
     assert x.shape[1] == (2 * w.K if act == 1 else w.K), (x.shape, w.K, act)
-    assert act != 2 or w.flags & 1, "act=2 needs a weight prepared with gate_up=True"
     if out is None:
         out = torch.empty((M, w.N // 2 if act == 2 else w.N), dtype=torch.float16, device=x.device)
     ws.ensure(w.workspace_bytes(M))
@@ -285,10 +350,14 @@ PARTIAL_MAX_M = 256  # rows up to which a GEMM may leave its split-K sum to the 
 def gptq_gemm_partial(x: torch.Tensor, w: GptqWeight, bias=None, act: int = 0) -> Partial:
     """Launch the GEMM but leave the split-K reduce (and bias) to the consumer.  Slabs are stored in 32-row units:
     [ceil(M/32)][S][32][ld]."""
-    assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] <= PARTIAL_MAX_M
     lib = load_library()
-    M = x.shape[0]
-    key = (M + 63) // 64 if M > 32 else 0  # the plan depends on M only through its pass count
+    if isinstance(x, FragAct):  # decode, <= 32 rows: the fragment-order kernel and ITS split plan
+        assert x.K == w.K and act == 0 and w.perm is None
+        M, key, xp, ldx = x.M, "frag", _ptr(x.buf), LD_FRAGMENTS
+    else:
+        assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] <= PARTIAL_MAX_M
+        M = x.shape[0]
+        key, xp, ldx = ((M + 63) // 64 if M > 32 else 0), _ptr(x), x.stride(0)  # plan depends on M through its pass count
     plan = w.partial_plan.get(key)  # (slab bytes, S, ld): asked from the library once per weight and pass count
     if plan is None:
         nbytes = lib.tgis_gptq_gemm_partial_bytes(M, w.K, w.N)
@@ -296,7 +365,7 @@ def gptq_gemm_partial(x: torch.Tensor, w: GptqWeight, bias=None, act: int = 0) -
         S = _c_int()
         ld = _c_i64()
         _check(
-            lib.tgis_gptq_gemm_f16_partial(_ptr(x), x.stride(0), _ptr(w.image), _ptr(w.perm), M, w.K, w.N,
+            lib.tgis_gptq_gemm_f16_partial(xp, ldx, _ptr(w.image), _ptr(w.perm), M, w.K, w.N,
                                            w.groups, act, _ptr(slabs), nbytes, ctypes.byref(S), ctypes.byref(ld),
                                            _stream()), "tgis_gptq_gemm_f16_partial")
         w.partial_plan[key] = (nbytes, S.value, ld.value)
@@ -304,7 +373,7 @@ def gptq_gemm_partial(x: torch.Tensor, w: GptqWeight, bias=None, act: int = 0) -
     nbytes, S, ld = plan
     slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     _check(
-        lib.tgis_gptq_gemm_f16_partial(_ptr(x), x.stride(0), _ptr(w.image), _ptr(w.perm), M, w.K, w.N,
+        lib.tgis_gptq_gemm_f16_partial(xp, ldx, _ptr(w.image), _ptr(w.perm), M, w.K, w.N,
                                        w.groups, act, _ptr(slabs), nbytes, None, None, _stream()),
         "tgis_gptq_gemm_f16_partial")
     return Partial(slabs, S, ld, M, w.N, bias)
@@ -333,15 +402,19 @@ def gptq_gemm_rope(x: torch.Tensor, w: GptqWeight, bias, cos, sin, positions, sl
     """qkv projection + rotary embedding + cache write in one launch (decode, M <= 64; `w` is the rope image of the fused
     qkv weight).  Returns a [M, (H + 2 Hkv) D] tensor whose first H D columns hold the rotated q (the k / v columns are not
     written: they went straight into their cache pages)."""
-    assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == w.K
+    if isinstance(x, FragAct):
+        assert x.K == w.K
+        M, xp, ldx = x.M, _ptr(x.buf), LD_FRAGMENTS
+    else:
+        assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == w.K
+        M, xp, ldx = x.shape[0], _ptr(x), x.stride(0)
     assert w.flags & 2 and w.N == (H + 2 * Hkv) * D
     assert positions.dtype == torch.int32 and slots.dtype == torch.int32 and cos.dtype == torch.float16
     assert cos.shape[1] * 2 == D, "the fused epilogue covers the full rotary span only"
-    M = x.shape[0]
     if out is None:
         out = torch.empty((M, w.N), dtype=torch.float16, device=x.device)
     _check(
-        load_library().tgis_gptq_gemm_rope_f16(_ptr(x), x.stride(0), _ptr(w.image), _ptr(bias), _ptr(positions), _ptr(slots),
+        load_library().tgis_gptq_gemm_rope_f16(xp, ldx, _ptr(w.image), _ptr(bias), _ptr(positions), _ptr(slots),
                                                _ptr(cos), _ptr(sin), _ptr(out), out.stride(0), _ptr(k_pool), _ptr(v_pool),
                                                M, w.K, w.N, w.groups, H, Hkv, D, _stream()),
         "tgis_gptq_gemm_rope_f16")
@@ -439,31 +512,38 @@ def clear_error() -> None:
 
 
 # ---- norms --------------------------------------------------------------------------------------------
-def rmsnorm_residual(x, residual, weight, eps: float, y=None, res_out=None):
-    """(y, res) = fused add + RMSNorm; mirrors LlamaRMSNorm.forward (flash_llama_modeling.py:113-152)."""
+def rmsnorm_residual(x, residual, weight, eps: float, y=None, res_out=None, frag: bool = False):
+    """(y, res) = fused add + RMSNorm; mirrors LlamaRMSNorm.forward (flash_llama_modeling.py:113-152).
+    frag (rows <= 32, f16): y is returned as a FragAct, the layout the int4 GEMM behind the norm reads."""
+    rows, hidden = x.shape
+    yf = None
+    if frag:
+        assert y is None and rows <= 32 and hidden % 64 == 0 and x.dtype == torch.float16
+        yf = FragAct.empty(rows, hidden, x.device)
+        y, ldy = yf.buf, LD_FRAGMENTS
+    else:
+        ldy = hidden
     if isinstance(x, Partial):
-        rows, hidden = x.shape
         if y is None:
             y = torch.empty((rows, hidden), dtype=x.dtype, device=x.device)
         if res_out is None:
-            res_out = torch.empty_like(y)  # always materialised: it is the reduced (+residual) stream
+            res_out = torch.empty((rows, hidden), dtype=x.dtype, device=x.device)  # the reduced (+ residual) stream
         _check(
             load_library().tgis_rmsnorm_residual_partial(_ptr(x.slabs), x.S, x.ld, _ptr(x.bias), _ptr(residual),
-                                                         _ptr(weight), _ptr(y), _ptr(res_out), rows, hidden,
+                                                         _ptr(weight), _ptr(y), ldy, _ptr(res_out), rows, hidden,
                                                          float(eps), dtype_code(x.dtype), _stream()),
             "tgis_rmsnorm_residual_partial")
-        return y, res_out
+        return (yf if frag else y), res_out
     assert x.dim() == 2 and x.is_contiguous()
-    rows, hidden = x.shape
     if y is None:
         y = torch.empty_like(x)
     if res_out is None:
         res_out = torch.empty_like(x) if residual is not None else x
     _check(
-        load_library().tgis_rmsnorm_residual(_ptr(x), _ptr(residual), _ptr(weight), _ptr(y),
+        load_library().tgis_rmsnorm_residual(_ptr(x), _ptr(residual), _ptr(weight), _ptr(y), ldy,
                                              _ptr(res_out) if residual is not None else None, rows, hidden,
                                              float(eps), dtype_code(x.dtype), _stream()), "tgis_rmsnorm_residual")
-    return y, res_out
+    return (yf if frag else y), res_out
 
 
 def layernorm_residual(x, residual, weight, bias, eps: float, y=None, res_out=None):
@@ -540,13 +620,20 @@ def attn_workspace_bytes(total_q: int, H: int, Hkv: int, D: int, num_splits: int
 
 def attn_paged(q, ld_q: int, k_pool, v_pool, block_tables, ctx_lens, cu_seqlens_q, out, B: int, H: int, Hkv: int,
                D: int, max_q_len: int, max_ctx: int, scale: float, num_splits: int, ws: Optional[Workspace]):
-    """q is a (view into a) [T, *] activation whose row stride is ld_q elements; out [T, H*D]."""
+    """q is a (view into a) [T, *] activation whose row stride is ld_q elements; out [T, H*D], or (decode, B <= 32) a
+    FragAct of that shape for the o_proj GEMM."""
     assert block_tables.dtype == torch.int32 and ctx_lens.dtype == torch.int32 and cu_seqlens_q.dtype == torch.int32
-    assert block_tables.is_contiguous() and out.is_contiguous()
+    assert block_tables.is_contiguous()
+    if isinstance(out, FragAct):
+        assert max_q_len == 1 and out.K == H * D and out.M == B
+        optr, ldo = _ptr(out.buf), LD_FRAGMENTS
+    else:
+        assert out.is_contiguous()
+        optr, ldo = _ptr(out), H * D
     wptr, wbytes = (ws.ptr, ws.nbytes) if ws is not None else (None, 0)
     _check(
         load_library().tgis_attn_paged(_ptr(q), ld_q, _ptr(k_pool), _ptr(v_pool), _ptr(block_tables),
-                                       block_tables.shape[1], _ptr(ctx_lens), _ptr(cu_seqlens_q), _ptr(out), B, H,
+                                       block_tables.shape[1], _ptr(ctx_lens), _ptr(cu_seqlens_q), optr, ldo, B, H,
                                        Hkv, D, max_q_len, max_ctx, float(scale), dtype_code(q.dtype), num_splits,
                                        wptr, wbytes, _stream()), "tgis_attn_paged")
     return out

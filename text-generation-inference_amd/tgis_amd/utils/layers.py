@@ -155,10 +155,28 @@ class Ex4bitLinearV2:
                                                              device=self.device)
         return buf
 
-    def forward(self, x: torch.Tensor, act: int = 0, partial: bool = False):
-        """partial=True (decode-sized M only): return native.Partial — the consumer kernel finishes the split-K sum."""
+    def wants_fragments(self, rows: int, act: int = 0) -> bool:
+        """Should the producer of this linear's operand write it in fragment order (native.FragAct) for `rows` decode
+        rows?  act: 0 plain / partial, 2 the SiLU * up image, 3 the rope image (the fused qkv + rotary launch)."""
         if self.q_handle is None:
             self.post_init()
+        if act == 2 and not self.gate_up:
+            act = 0
+        w = self.rope_handle if act == 3 else self.q_handle
+        return w is not None and rows <= 32 and native.gptq_fragments_ok(rows, w, act)
+
+    def forward(self, x, act: int = 0, partial: bool = False, out_frag: bool = False):
+        """partial=True (decode-sized M only): return native.Partial — the consumer kernel finishes the split-K sum.
+        x may be a native.FragAct (decode, <= 32 rows; see wants_fragments); out_frag: the SiLU * up output leaves as one."""
+        if self.q_handle is None:
+            self.post_init()
+        if isinstance(x, native.FragAct):
+            if self.gate_up:
+                return native.gptq_gemm(x, self.q_handle, workspace(x.device), bias=self.bias, act=2, out_frag=out_frag)
+            assert act == 0
+            if partial and DEFER_REDUCE:
+                return native.gptq_gemm_partial(x, self.q_handle, bias=self.bias)
+            return native.gptq_gemm(x, self.q_handle, workspace(x.device), bias=self.bias)
         if self.gate_up:
             # output is the activated [M, I] tensor
             if x.shape[0] <= self._fused_rows(2):
