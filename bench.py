@@ -78,8 +78,10 @@ def cpu_baseline(cfg, quantize, B, ctx, groupsize=128):
 
     threads = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(threads)
-    E, I, H = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
-    Hkv = cfg.num_key_value_heads
+    bigcode = hasattr(cfg, "n_inner")
+    E, H = cfg.hidden_size, cfg.num_attention_heads
+    I = cfg.n_inner if bigcode else cfg.intermediate_size
+    Hkv = 1 if bigcode else cfg.num_key_value_heads
     D = E // H
     g = torch.Generator().manual_seed(0)
 
@@ -89,10 +91,12 @@ def cpu_baseline(cfg, quantize, B, ctx, groupsize=128):
             return ops_ref.gptq_dequant(qw, qz, sc, gi, groupsize)
         return torch.randn(k, n, generator=g) * 0.02
 
-    wq, wo, wgu, wd = weight(E, (H + 2 * Hkv) * D), weight(E, E), weight(E, 2 * I), weight(I, E)
+    wo = weight(E, E)
     norm_w = torch.ones(E)
-    Kc = torch.randn(B, Hkv, ctx, D, generator=g)
-    Vc = torch.randn(B, Hkv, ctx, D, generator=g)
+    if not bigcode:
+        wq, wgu, wd = weight(E, (H + 2 * Hkv) * D), weight(E, 2 * I), weight(I, E)
+        Kc = torch.randn(B, Hkv, ctx, D, generator=g)
+        Vc = torch.randn(B, Hkv, ctx, D, generator=g)
     x = torch.randn(B, E, generator=g)
     cos, sin = ops_ref.rope_tables(D, 10000.0, ctx, torch.float32)
     pos = torch.full((B,), ctx - 1, dtype=torch.int64)
@@ -113,6 +117,26 @@ def cpu_baseline(cfg, quantize, B, ctx, groupsize=128):
         h2, residual = ops_ref.rmsnorm_residual(o @ wo, residual, norm_w, cfg.rms_norm_eps)
         return ops_ref.silu_mul(h2 @ wgu, I) @ wd, residual
 
+    if bigcode:
+        # GPT-BigCode layer (flash_santacoder_modeling.py:226-330 as restated in oracle/santacoder_ref.py): LayerNorm,
+        # c_attn with ONE k / v head, attention of the H query heads over it, c_proj, LayerNorm, c_fc -> gelu -> c_proj
+        wqkv, wfc, wpr = weight(E, (H + 2) * D), weight(E, I), weight(I, E)
+        ln_b = torch.zeros(E)
+        Kc1 = torch.randn(B, ctx, D, generator=g)
+        Vc1 = torch.randn(B, ctx, D, generator=g)
+        tanh = getattr(cfg, "activation_function", "gelu_pytorch_tanh") != "gelu"
+
+        def layer(x, residual):  # noqa: F811
+            h, residual = ops_ref.layernorm_residual(x, residual, norm_w, ln_b, cfg.layer_norm_epsilon)
+            qkv = h @ wqkv
+            q = qkv[:, :H * D].reshape(B, H, D)
+            Kc1[:, -1] = qkv[:, H * D:(H + 1) * D]
+            Vc1[:, -1] = qkv[:, (H + 1) * D:]
+            sc = torch.einsum("bhd,btd->bht", q, Kc1) * (D ** -0.5)
+            o = torch.einsum("bht,btd->bhd", torch.softmax(sc, dim=-1), Vc1).reshape(B, H * D)
+            h2, residual = ops_ref.layernorm_residual(o @ wo, residual, norm_w, ln_b, cfg.layer_norm_epsilon)
+            return ops_ref.gelu(h2 @ wfc, tanh) @ wpr, residual
+
     layer(x, x)  # warm-up
     t0 = time.perf_counter()
     reps = 0
@@ -127,8 +151,11 @@ def cpu_baseline(cfg, quantize, B, ctx, groupsize=128):
     step_s = t_layer * cfg.num_hidden_layers + t_head
     return {"value": round(B / step_s, 2), "unit": "tokens/s", "cores": threads, "kind": "port",
             "ms_per_step": round(step_s * 1e3, 1),
-            "sample": f"one decoder layer of one decode step at B={B}, ctx={ctx}, fp32, {reps} repetitions, "
-                      f"x{cfg.num_hidden_layers} layers + lm_head/greedy"}
+            # what this number is: OUR fp32 restatement (oracle/), one layer timed and extrapolated — not the reference's
+            # own process (its CPU path needs its pinned transformers / torch: tests/golden/make_*fixtures.py)
+            "sample": f"oracle/ port, not the reference binary: one {'GPT-BigCode' if bigcode else 'Llama'} decoder layer of "
+                      f"one decode step at B={B}, ctx={ctx}, fp32, whole (unsharded) model, {reps} repetitions, "
+                      f"extrapolated x{cfg.num_hidden_layers} layers + measured lm_head/greedy"}
 
 
 def fused_rope_launches_per_step(lm):
@@ -148,28 +175,30 @@ def pmc_traffic(config, B, ctx_mean):
     for 16 B/lane streaming reads on gfx950).  Counters cannot be collected inside the timed run, so the figure is read
     from profiles/ and only reported for the workload it was measured on; otherwise null."""
     if (config, B, ctx_mean) != ("llama2-7b-gptq", 32, 1024):
-        return None
+        return None, None
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_attn_traffic.json")))
     if not files:
-        return None
+        return None, None
     d = json.load(open(files[-1]))
     if d.get("fetch_bytes_per_launch_corrected") is None:
-        return None
-    return int(d["fetch_bytes_per_launch_corrected"] + (d.get("write_bytes_per_launch_uncalibrated") or 0))
+        return None, None
+    return int(d["fetch_bytes_per_launch_corrected"] + (d.get("write_bytes_per_launch_uncalibrated") or 0)), \
+        "profiles/" + os.path.basename(files[-1])
 
 
 def pmc_gemm_traffic(config, B, ctx_mean):
     """HBM bytes per int4-GEMM launch (average over the four shapes of a layer) from the same counter passes
     (profiles/r*_gemm_traffic.json); null for workloads it was not collected on."""
     if (config, B, ctx_mean) != ("llama2-7b-gptq", 32, 1024):
-        return None
+        return None, None
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_gemm_traffic.json")))
     if not files:
-        return None
+        return None, None
     d = json.load(open(files[-1]))
     if d.get("fetch_bytes_per_launch_corrected") is None:
-        return None
-    return int(d["fetch_bytes_per_launch_corrected"] + (d.get("write_bytes_per_launch_uncalibrated") or 0))
+        return None, None
+    return int(d["fetch_bytes_per_launch_corrected"] + (d.get("write_bytes_per_launch_uncalibrated") or 0)), \
+        "profiles/" + os.path.basename(files[-1])
 
 
 def bench_causal_lm_cpu(args):
@@ -403,9 +432,16 @@ def main():
             bytes_per_launch = B * ctx_timed_mean * 2 * Hkv_rank * D * 2 + B * 2 * Hkv_rank * D * 2
             avg_s = ms_attn * 1e-3 / max(n_attn, 1)
             achieved = bytes_per_launch / avg_s / 1e9
+            traffic, traffic_src = pmc_traffic(args.config, B, ctx_mean)
             roofline = {"bound": "hbm", "kernel": "attn_paged_kernel (decode)", "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": pmc_traffic(args.config, B, ctx_mean), "launches": int(n_attn),
+                        "traffic": traffic,
+                        # counters cannot be collected inside a timed run: the figure is the committed --pmc pass of this
+                        # command (tools/profile_round.sh), not a measurement of THIS run
+                        "traffic_source": traffic_src and f"{traffic_src} (committed rocprofv3 --pmc pass, not this run)",
+                        # avg_launch_us comes from a second, eager pass of the same workload (HIP events around every
+                        # launch); ms_per_step is the captured-graph pass
+                        "pass": "eager, HIP events on the launch stream", "launches": int(n_attn),
                         "avg_launch_us": round(avg_s * 1e6, 2),
                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
                         "gemm_launches": int(n_gemm), "gemm_avg_launch_us": round(ms_gemm * 1e3 / max(n_gemm, 1), 2)}
@@ -418,11 +454,14 @@ def main():
             if n_gemm:
                 g_avg_s = ms_gemm * 1e-3 / n_gemm
                 g_bytes = gemm_bytes_step / max(per_step, 1)
-                roofline_gemm = {"bound": "hbm", "kernel": ("gptq_gemm_kernel" if quantize == "gptq" else "dense_gemm_kernel")
-                                 + f" ({per_step:.0f} launches per step)",
+                g_traffic, g_traffic_src = pmc_gemm_traffic(args.config, B, ctx_mean)
+                roofline_gemm = {"bound": "hbm", "kernel": ("gptq_wide_kernel / gptq_gemm_kernel" if quantize == "gptq"
+                                                            else "dense_gemm_kernel") + f" ({per_step:.0f} launches per step)",
                                  "achieved": round(g_bytes / g_avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(g_bytes / g_avg_s / 1e9 / HBM_PEAK_GBS, 4),
-                                 "traffic": pmc_gemm_traffic(args.config, B, ctx_mean),
+                                 "traffic": g_traffic,
+                                 "traffic_source": g_traffic_src and f"{g_traffic_src} (committed rocprofv3 --pmc pass, not this run)",
+                                 "pass": "eager, HIP events on the launch stream",
                                  "launches": int(n_gemm), "avg_launch_us": round(g_avg_s * 1e6, 2),
                                  "algorithmic_bytes_per_launch": int(g_bytes),
                                  # one GEMM launch per layer may carry the rotary embedding + cache write in its epilogue
@@ -452,7 +491,9 @@ def main():
                    # eagerly issued collectives only (segments / eager mode); inside one captured graph they cannot be
                    # bracketed and are part of ms_per_step
                    "collectives_per_step": (round(len(coll_us) / K, 1) if coll_us else None),
-                   "collective_avg_us": (round(sum(coll_us) / len(coll_us), 2) if coll_us else None)},
+                   "collective_avg_us": (round(sum(coll_us) / len(coll_us), 2) if coll_us else None),
+                   # what ONE rank streams per step (weights / tp, its kv heads' pages, the head / tp)
+                   "algorithmic_bytes_per_rank_step": int(ab["total"])},
         "step_roofline": {"algorithmic_bytes_per_step": int(ab["total"]), "ms_at_hbm_peak": round(step_roof_ms, 4),
                           "frac_of_hbm_peak": round(step_roof_ms / (elapsed / K * 1e3), 4)},
     }
@@ -460,7 +501,9 @@ def main():
         out["roofline"] = roofline
     if roofline_gemm is not None:
         out["roofline_gemm"] = roofline_gemm
-    if rank == 0 and not args.no_cpu_baseline and world == 1 and not bigcode:  # the CPU port below is the Llama layer
+    if rank == 0 and not args.no_cpu_baseline:
+        # next to every line (N > 1 too: rank 0 times it while the others wait at the final barrier): the whole,
+        # unsharded model on this host's cores
         out["cpu_baseline"] = cpu_baseline(cfg, quantize, B, int(round(ctx_timed_mean)))
     if rank == 0:
         print(json.dumps(out), flush=True)

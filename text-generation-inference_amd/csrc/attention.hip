@@ -526,6 +526,9 @@ static void launch_attn_one(const AttnArgs& a, dim3 grid, hipStream_t st) {
     if constexpr (CH > 1 && NW == 4) {
         if (pipe_env != 0) return launch_attn_pipe<T, D, NW, CH, true>(a, grid, st);
     }
+    if constexpr (CH == 1 && (NW == 2 || NW == 4)) {
+        if (pipe_env == 2) return launch_attn_pipe<T, D, NW, CH, true>(a, grid, st);
+    }
     launch_attn_pipe<T, D, NW, CH, false>(a, grid, st);
 }
 
