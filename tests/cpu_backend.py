@@ -24,9 +24,19 @@ class _GptqWeight:
         self.K, self.N = qweight.shape[0] * 8, qweight.shape[1]
         self.groups = qzeros.shape[0]
         self.perm = None
+        self.in_features = self.K
+        explicit = None
+        if isinstance(g_idx, tuple):  # act-order row shard: rows in image order + gather index (-1 = zero activation)
+            _, explicit, self.in_features = g_idx
+            g_idx = None
         gi = None if g_idx is None else g_idx.cpu().numpy()
         self.w = ops_ref.gptq_dequant(qweight.cpu().numpy(), qzeros.cpu().numpy(), scales.float().cpu(), gi,
                                       self.K // self.groups)
+        if explicit is not None:  # fold the gather into the matrix: W_x[c] = sum of the image rows that read column c
+            wx = torch.zeros((self.in_features, self.N), dtype=self.w.dtype)
+            real = explicit >= 0
+            wx[explicit[real].long()] = self.w[real]
+            self.w = wx
 
     def workspace_bytes(self, M):
         return 0
@@ -51,7 +61,7 @@ def _act(x, K):
 
 
 def _gptq_gemm(x, w, ws, bias=None, act=0, out=None):
-    xf = _act(x, w.K) if act == 1 else x.float()
+    xf = _act(x, w.in_features) if act == 1 else x.float()
     y = xf @ w.w
     if bias is not None:
         y = y + bias.float()

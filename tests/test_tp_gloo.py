@@ -190,3 +190,99 @@ def test_tp_ranks_agree_on_the_smallest_page_pool():
             p.join(120)
             assert p.exitcode == 0
         assert dict(ret) == {0: 863, 1: 863}
+
+
+def _act_order_tensors(K, N, gs, seed):
+    from oracle import ops_ref
+
+    qw, qz, sc, gi = ops_ref.make_gptq_tensors(K, N, gs, seed=seed, act_order=True)
+    t = {"p.qweight": torch.from_numpy(qw), "p.qzeros": torch.from_numpy(qz), "p.scales": torch.from_numpy(sc),
+         "p.g_idx": torch.from_numpy(gi).to(torch.int32)}
+    return (qw, qz, sc, gi), t
+
+
+@pytest.mark.parametrize("K,gs,world", [(1024, 128, 2), (2048, 128, 4), (448, 64, 2)])
+def test_act_order_row_shards_carry_their_own_permutation(K, gs, world):
+    """Act-order GPTQ under row tensor parallelism (the reference's g_idx fallback, utils/weights.py:150-156,190-196): each
+    rank gets its rows sorted by group, runs padded to 32 rows, scales / zeros looked up in the FULL tables.  Every real
+    image row must dequantise to exactly the row of the unsharded matrix it gathers, pad rows read a zero activation."""
+    from oracle import ops_ref
+    from tgis_amd.utils.dist import FakeGroup
+    from tgis_amd.utils.weights import DictWeights
+
+    N = 64
+    (qw, qz, sc, gi), t = _act_order_tensors(K, N, gs, seed=K + world)
+    full = ops_ref.gptq_dequant(qw, qz, sc, gi, gs)  # [K, N], natural row order
+    rows = K // world
+    for rank in range(world):
+        w = DictWeights(t, torch.device("cpu"), torch.float16, FakeGroup(rank, world))
+        w.gptq_bits, w.gptq_groupsize = 4, gs
+        lqw, lqz, lsc, lgi, bits, lgs, _ = w.get_multi_weights_row("p", "gptq")
+        tag, perm, xcols = lgi
+        Kp = lqw.shape[0] * 8
+        assert tag == "perm" and xcols == rows and perm.shape == (Kp,) and lgs == 32 and Kp % 32 == 0
+        assert lqz.shape[0] == lsc.shape[0] == Kp // 32
+        real = perm >= 0
+        assert int(real.sum()) == rows and sorted(perm[real].tolist()) == list(range(rows)), "a permutation of the shard"
+        local = ops_ref.gptq_dequant(lqw.numpy(), lqz.numpy(), lsc.numpy(), None, lgs)
+        assert torch.equal(local[real], full[rank * rows + perm[real].long()])
+        # pad rows hold zero nibbles: whatever they dequantise to is multiplied by a zero activation
+        nib = ((lqw.unsqueeze(1) >> (torch.arange(8, dtype=torch.int32) * 4).view(1, 8, 1)) & 15).reshape(Kp, N)
+        assert int(nib[~real].abs().sum()) == 0
+
+
+def _act_order_worker(rank, world, port, ret):
+    import pytest as _pytest
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "text-generation-inference_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from tests import cpu_backend
+
+    cpu_backend.install(_pytest.MonkeyPatch())
+    import types
+
+    from tgis_amd.utils.dist import initialize_torch_distributed
+    from tgis_amd.utils.layers import TensorParallelRowLinear
+    from tgis_amd.utils.weights import DictWeights
+
+    torch.set_num_threads(2)
+    K, N, gs, M = 1024, 96, 128, 5
+    _, t = _act_order_tensors(K, N, gs, seed=77)
+    pg = initialize_torch_distributed(world, rank)
+    w = DictWeights(t, torch.device("cpu"), torch.float16, pg)
+    w.gptq_bits, w.gptq_groupsize = 4, gs
+    lin = TensorParallelRowLinear.load(types.SimpleNamespace(quantize="gptq"), "p", w, bias=False)
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(M, K, generator=g) * 0.5).half()
+    rows = K // world
+    y = lin(x[:, rank * rows:(rank + 1) * rows].contiguous())
+    ret[rank] = y.float()
+
+
+def test_act_order_row_parallel_linear_world2_matches_the_unsharded_formula():
+    """Two gloo ranks: TensorParallelRowLinear over act-order shards + all-reduce == ops_ref.gptq_linear on the whole matrix."""
+    from oracle import ops_ref
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_act_order_worker, args=(r, world, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(180)
+            assert p.exitcode == 0
+        got = dict(ret)
+    (qw, qz, sc, gi), _ = _act_order_tensors(1024, 96, 128, seed=77)
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(5, 1024, generator=g) * 0.5).half()
+    want = ops_ref.gptq_linear(x, qw, qz, sc, gi, 128, None).float()
+    for r in range(world):
+        assert torch.allclose(got[r], want, rtol=4e-3, atol=4e-3 * float(want.abs().mean()) + 1e-3), r

@@ -238,3 +238,38 @@ def test_tp2_sampling_ranks_agree(gpu_device):
     assert all(np.array_equal(a, b) for a, b in zip(logits0, logits1))
     greedy = [[int(np.argmax(l[r])) for r in range(2, len(PROMPTS))] for l in logits0]
     assert [row[2:] for row in ids0] == greedy  # the greedy neighbours are untouched by the sampled rows
+
+
+@pytest.mark.parametrize("K,N,gs,world,M", [(4096, 4096, 128, 2, 32), (11008, 4096, 128, 4, 7), (1024, 96, 128, 2, 70),
+                                             (4096, 512, 128, 2, 2000)])
+def test_act_order_row_parallel_shards_on_the_kernels(gpu_device, K, N, gs, world, M):
+    """Act-order GPTQ under row tensor parallelism through the real kernels: every rank's shard (rows sorted by group, runs
+    padded to 32 rows with the gather index -1, scales / zeros from the full tables: utils/weights.py, the reference's
+    g_idx fallback utils/weights.py:150-156,190-196) run one after the other on this GPU, partial results summed as the
+    all-reduce would, against ops_ref.gptq_linear on the whole matrix with its random g_idx.  M = 70: 64-row passes;
+    M = 2000: the dequantise + library GEMM path."""
+    import types
+
+    from oracle import ops_ref
+    from tgis_amd.utils.dist import FakeGroup
+    from tgis_amd.utils.layers import TensorParallelRowLinear
+    from tgis_amd.utils.weights import DictWeights
+
+    qw, qz, sc, gi = ops_ref.make_gptq_tensors(K, N, gs, seed=K + N, act_order=True)
+    t = {"p.qweight": torch.from_numpy(qw), "p.qzeros": torch.from_numpy(qz), "p.scales": torch.from_numpy(sc),
+         "p.g_idx": torch.from_numpy(gi).to(torch.int32)}
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, K, generator=g) * 0.5).half()
+    want = ops_ref.gptq_linear(x, qw, qz, sc, gi, gs, None).float()
+    rows = K // world
+    total = torch.zeros((M, N), dtype=torch.float32)
+    for rank in range(world):
+        w = DictWeights(t, gpu_device, torch.float16, FakeGroup(rank, world))
+        w.gptq_bits, w.gptq_groupsize = 4, gs
+        lin = TensorParallelRowLinear.load(types.SimpleNamespace(quantize="gptq"), "p", w, bias=False).linear
+        y = lin(x[:, rank * rows:(rank + 1) * rows].contiguous().to(gpu_device))
+        assert lin.q_handle.perm is not None and lin.q_handle.in_features == rows
+        total += y.float().cpu()
+    err = (total - want).abs()
+    bound = 4e-3 * want.abs() + 4e-3 * float(want.abs().mean()) + 1e-3  # world f16 roundings of partial sums
+    assert bool((err <= bound).all()), f"max err {float(err.max()):.4g}"

@@ -273,9 +273,9 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
                 const GLOBAL_AS f16* xr = (const GLOBAL_AS f16*)(xb + rowoff[j]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    int ksrc = a.perm[kc + e];
-                    v[e] = xr[ksrc];
-                    if (ACT == 1) u[e] = xr[a.K + ksrc];
+                    const int ksrc = a.perm[kc + e];  // -1: a pad row of an act-order row shard (utils/weights.py) reads 0
+                    v[e] = ksrc >= 0 ? xr[ksrc] : (f16)0.f;
+                    if (ACT == 1) u[e] = ksrc >= 0 ? xr[a.K + ksrc] : (f16)0.f;
                 }
             }
             xg[j] = v;

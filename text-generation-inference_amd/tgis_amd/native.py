@@ -270,8 +270,14 @@ class GptqWeight:
         qzeros = qzeros.contiguous()
         scales = scales.to(torch.float16).contiguous()
         self.perm = None
+        self.in_features = self.K  # columns of the activation (differs from K only for padded act-order row shards)
         gi = None
         perm_buf = None
+        explicit = None
+        if isinstance(g_idx, tuple):  # ("perm", gather index [K] with -1 = zero, activation columns): rows are in image order
+            _, explicit, self.in_features = g_idx
+            assert explicit.numel() == self.K
+            g_idx = None
         if g_idx is not None:
             gi = g_idx.to("cpu", torch.int32).contiguous()
             perm_buf = torch.empty(self.K, dtype=torch.int32, device=dev)
@@ -285,6 +291,8 @@ class GptqWeight:
             trivial = bool((gi == (torch.arange(self.K, dtype=torch.int32) // gs)).all())
             if not trivial:
                 self.perm = perm_buf
+        if explicit is not None:
+            self.perm = explicit.to(dev, torch.int32).contiguous()
         torch.cuda.current_stream().synchronize()  # qweight/qzeros/scales may be freed by the caller
 
     def workspace_bytes(self, M: int) -> int:
@@ -319,7 +327,8 @@ def gptq_gemm(x, w: GptqWeight, ws: Workspace, bias=None, act: int = 0, out=None
     assert not out_frag, "a fragment-order output needs a fragment-order activation"
     assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1
     M = x.shape[0]
-    assert x.shape[1] == (2 * w.K if act == 1 else w.K), (x.shape, w.K, act)
+    assert x.shape[1] == (2 * w.in_features if act == 1 else w.in_features), (x.shape, w.in_features, act)
+    assert act != 1 or w.in_features == w.K
     if out is None:
         out = torch.empty((M, w.N // 2 if act == 2 else w.N), dtype=torch.float16, device=x.device)
     ws.ensure(w.workspace_bytes(M))

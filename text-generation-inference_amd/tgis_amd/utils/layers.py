@@ -113,7 +113,8 @@ class Ex4bitLinearV2:
         assert bits == 4
         self.device = qweight.device
         self.qweight, self.qzeros, self.scales = qweight, qzeros, scales
-        self.g_idx = g_idx.cpu() if g_idx is not None else None
+        # ("perm", gather index, x columns): an explicit activation permutation (act-order row shards, utils/weights.py)
+        self.g_idx = g_idx if isinstance(g_idx, tuple) else (g_idx.cpu() if g_idx is not None else None)
         self.bias = bias
         self.bits, self.groupsize = bits, groupsize
         self.height = qweight.shape[0] * 8
@@ -193,7 +194,11 @@ class Ex4bitLinearV2:
     def _large_m(self, x: torch.Tensor) -> torch.Tensor:
         """prefill-sized M: dequantise once into scratch, then a library GEMM (exllamav2.py:87 "M > 50")."""
         if self.q_handle.perm is not None:
-            x = x.index_select(1, self.q_handle.perm.long())
+            perm = self.q_handle.perm.long()
+            if self.q_handle.in_features != self.q_handle.K:  # padded shard: index -1 reads a zero column
+                x = torch.nn.functional.pad(x, (0, 1))
+                perm = torch.where(perm < 0, torch.full_like(perm, x.shape[1] - 1), perm)
+            x = x.index_select(1, perm)
         w = self._dequant_scratch()
         native._check(native.load_library().tgis_gptq_dequant_f16(
             self.q_handle.image.data_ptr(), w.data_ptr(), self.height, self.width, self.q_handle.groups,

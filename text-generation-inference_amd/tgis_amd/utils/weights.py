@@ -93,9 +93,11 @@ class _Base:
                 trivial = torch.equal(g_idx_full.cpu().to(torch.int32),
                                       (torch.arange(K, dtype=torch.int32) // gs))
                 if not trivial and not bool((g_idx_full == 0).all()):
-                    raise NotImplementedError(
-                        "act-order GPTQ with row tensor parallelism needs the activation permutation across "
-                        "ranks (the reference falls back to its Triton kernel here); not supported")
+                    # The reference leaves exllama here and serves the shard with its g_idx (Triton) kernel: this rank's
+                    # rows of qweight, the FULL scales / zero points, the rank's slice of g_idx
+                    # (utils/weights.py:150-156,190-196; W[k] = (q[k] - z[g_idx[k]] - 1) * s[g_idx[k]],
+                    # utils/gptq/quant_linear.py:159-192).  Same values here, in the streaming kernel's layout.
+                    return self._act_order_row_shard(prefix, bits, groupsize, g_idx_full)
             qweight = self.get_sharded(f"{prefix}.qweight", dim=0)
             rows = qweight.shape[0] * (32 // bits)  # this rank's K
             if groupsize >= 0 and tp > 1 and rows % groupsize != 0:
@@ -121,6 +123,42 @@ class _Base:
             g_idx = g_idx_full if tp == 1 else None
             return (qweight, qzeros, scales, g_idx, bits, groupsize, bits == 4)
         return self.get_sharded(f"{prefix}.weight", dim=1)
+
+    def _act_order_row_shard(self, prefix: str, bits: int, groupsize: int, g_idx_full: torch.Tensor):
+        """Row shard of an act-order GPTQ matrix.  The rank's rows [start, start + rows) belong to arbitrary groups, each
+        group possibly present with any number of rows.  They are sorted by group (a permutation of the rank's OWN
+        activation columns, applied while the GEMM stages its operand), every group's run is padded to a multiple of 32
+        rows (pad rows: zero nibbles and the gather index -1, which reads as a zero activation), and each 32-row sub-group
+        carries a copy of its parent group's scale / zero point from the FULL tables: numerically the reference's
+        W[k] = (q[k] - z[g_idx[k]] - 1) * s[g_idx[k]] for k in the shard, in the layout the streaming kernel reads.
+        Returns the usual bundle with ("perm", gather index int32 [K']) in the g_idx slot and group size 32."""
+        SUB = 32
+        qweight = self.get_sharded(f"{prefix}.qweight", dim=0)
+        dev = qweight.device
+        per = 32 // bits
+        rows, N = qweight.shape[0] * per, qweight.shape[1]
+        start = self.process_group.rank() * rows
+        g = g_idx_full[start:start + rows].to("cpu", torch.int64)
+        order = torch.argsort(g, stable=True)
+        uniq, counts = torch.unique_consecutive(g[order], return_counts=True)
+        padded = (counts + SUB - 1) // SUB * SUB
+        Kp = int(padded.sum())
+        perm = torch.full((Kp,), -1, dtype=torch.int32)
+        parent = torch.empty(Kp // SUB, dtype=torch.int64)
+        pos = src = 0
+        for u, c, pc in zip(uniq.tolist(), counts.tolist(), padded.tolist()):
+            perm[pos:pos + c] = order[src:src + c].to(torch.int32)
+            parent[pos // SUB:(pos + pc) // SUB] = u
+            pos += pc
+            src += c
+        shifts = (torch.arange(per, dtype=torch.int32, device=dev) * bits).view(1, per, 1)
+        nib = ((qweight.unsqueeze(1) >> shifts) & ((1 << bits) - 1)).reshape(rows, N).to(torch.uint8)
+        nib = torch.cat([nib, torch.zeros((1, N), dtype=torch.uint8, device=dev)])  # row `rows`: the pad row
+        idx = torch.where(perm < 0, torch.full_like(perm, rows), perm).to(dev).long()
+        packed = (nib[idx].view(Kp // per, per, N).to(torch.int32) << shifts).sum(dim=1, dtype=torch.int32)
+        qzeros = self.get_tensor(f"{prefix}.qzeros")[parent.to(dev)].contiguous()
+        scales = self.get_tensor(f"{prefix}.scales")[parent.to(dev)].contiguous()
+        return (packed.contiguous(), qzeros, scales, ("perm", perm, rows), bits, SUB, bits == 4)
 
     def _get_gptq_params(self) -> Tuple[int, int]:
         if self.has("gptq_bits") and self.has("gptq_groupsize"):
