@@ -88,35 +88,9 @@ class LlamaRef:
         residual = None
         keep = None
         for l in range(self.L):
-            p = f"model.layers.{l}"
-            h, residual = ops_ref.rmsnorm_residual(x, residual, self._vec(f"{p}.input_layernorm.weight"), self.eps)
-            k = (h @ self._lin(f"{p}.self_attn.k_proj")).view(T, self.Hkv, self.D)
-            v = (h @ self._lin(f"{p}.self_attn.v_proj")).view(T, self.Hkv, self.D)
-            k = ops_ref.apply_rope(k, cos, sin)
             if last_only and l == self.L - 1:
                 keep = self._last_rows(seq_of_token)
-            rows = keep if keep is not None else list(range(T))
-            hq = h[rows] if keep is not None else h
-            q = (hq @ self._lin(f"{p}.self_attn.q_proj")).view(len(rows), self.H, self.D)
-            q = ops_ref.apply_rope(q, cos[rows], sin[rows])
-            attn = torch.empty((len(rows), self.H, self.D), dtype=torch.float32)
-            row_of = {r: j for j, r in enumerate(rows)}
-            for b in seqs:
-                idx = tok_idx[b]
-                past = state[b][l]
-                kb = k[idx] if past is None else torch.cat([past[0], k[idx]])
-                vb = v[idx] if past is None else torch.cat([past[1], v[idx]])
-                state[b][l] = (kb, vb)
-                qi = [row_of[i] for i in idx if i in row_of]  # the LAST len(qi) tokens of this run
-                attn[qi] = ops_ref.attention_varlen(q[qi], kb, vb, [0, len(qi)], [0, kb.shape[0]], self.D ** -0.5)
-            if keep is not None:
-                residual = residual[rows]
-            o = attn.reshape(len(rows), self.H * self.D) @ self._lin(f"{p}.self_attn.o_proj")
-            h2, residual = ops_ref.rmsnorm_residual(o, residual, self._vec(f"{p}.post_attention_layernorm.weight"),
-                                                    self.eps)
-            gate = h2 @ self._lin(f"{p}.mlp.gate_proj")
-            up = h2 @ self._lin(f"{p}.mlp.up_proj")
-            x = (torch.nn.functional.silu(gate) * up) @ self._lin(f"{p}.mlp.down_proj")
+            x, residual = self._layer(l, x, residual, cos, sin, seq_of_token, state, keep)
         if last_only and keep is None:  # no layers at all
             keep = self._last_rows(seq_of_token)
             x = x[keep]
@@ -124,6 +98,86 @@ class LlamaRef:
             return x if residual is None else x + residual
         hfin, _ = ops_ref.rmsnorm_residual(x, residual, self._vec("model.norm.weight"), self.eps)
         return hfin @ self._lin("lm_head")
+
+    def _layer(self, l: int, x, residual, cos, sin, seq_of_token: List[int], state, keep):
+        """Decoder layer l over the tokens of one forward (flash_llama_modeling.py:360-393); `keep` (last layer of a
+        last_only forward) = the rows whose queries / attention / MLP are computed at all.  Appends K/V to state[b][l]."""
+        T = len(seq_of_token)
+        seqs = sorted(set(seq_of_token), key=seq_of_token.index)
+        tok_idx = {b: [i for i, s in enumerate(seq_of_token) if s == b] for b in seqs}
+        p = f"model.layers.{l}"
+        h, residual = ops_ref.rmsnorm_residual(x, residual, self._vec(f"{p}.input_layernorm.weight"), self.eps)
+        k = (h @ self._lin(f"{p}.self_attn.k_proj")).view(T, self.Hkv, self.D)
+        v = (h @ self._lin(f"{p}.self_attn.v_proj")).view(T, self.Hkv, self.D)
+        k = ops_ref.apply_rope(k, cos, sin)
+        rows = keep if keep is not None else list(range(T))
+        hq = h[rows] if keep is not None else h
+        q = (hq @ self._lin(f"{p}.self_attn.q_proj")).view(len(rows), self.H, self.D)
+        q = ops_ref.apply_rope(q, cos[rows], sin[rows])
+        attn = torch.empty((len(rows), self.H, self.D), dtype=torch.float32)
+        row_of = {r: j for j, r in enumerate(rows)}
+        for b in seqs:
+            idx = tok_idx[b]
+            past = state[b][l]
+            kb = k[idx] if past is None else torch.cat([past[0], k[idx]])
+            vb = v[idx] if past is None else torch.cat([past[1], v[idx]])
+            state[b][l] = (kb, vb)
+            qi = [row_of[i] for i in idx if i in row_of]  # the LAST len(qi) tokens of this run
+            attn[qi] = ops_ref.attention_varlen(q[qi], kb, vb, [0, len(qi)], [0, kb.shape[0]], self.D ** -0.5)
+        if keep is not None:
+            residual = residual[rows]
+        o = attn.reshape(len(rows), self.H * self.D) @ self._lin(f"{p}.self_attn.o_proj")
+        h2, residual = ops_ref.rmsnorm_residual(o, residual, self._vec(f"{p}.post_attention_layernorm.weight"),
+                                                self.eps)
+        gate = h2 @ self._lin(f"{p}.mlp.gate_proj")
+        up = h2 @ self._lin(f"{p}.mlp.up_proj")
+        return (torch.nn.functional.silu(gate) * up) @ self._lin(f"{p}.mlp.down_proj"), residual
+
+    def generate_forced_layer_major(self, prompts: List[List[int]], forced: List[List[int]], keep_cache_layers=(0,)):
+        """generate_greedy(prompts, len(forced), forced) evaluated LAYER by layer instead of step by step: with every fed
+        token known in advance (teacher forcing) the prefill and all decode forwards go through layer l before anyone
+        touches layer l + 1, so each layer's weights are dequantised once and dropped — a 32-layer int4 model at width
+        4096 then needs one layer (0.8 GB fp32) on the host at a time.  Same functions, same order of arithmetic per
+        value; K/V are kept only for `keep_cache_layers`.  Returns the same per-step dicts."""
+        B = len(prompts)
+        n_steps = len(forced)
+        state = self.new_state(B)
+        self.last_state = state
+        emb = self._vec("model.embed_tokens.weight")
+        lengths = [len(p) for p in prompts]
+        passes = [(torch.tensor([t for p in prompts for t in p], dtype=torch.int64),
+                   torch.tensor([i for p in prompts for i in range(len(p))], dtype=torch.int64),
+                   [b for b, p in enumerate(prompts) for _ in p])]
+        for step in range(n_steps - 1):
+            passes.append((torch.tensor(forced[step], dtype=torch.int64),
+                           torch.tensor([n + step for n in lengths], dtype=torch.int64), list(range(B))))
+        xs = [emb[ids.long()] for ids, _, _ in passes]
+        rs = [None] * len(passes)
+        ropes = []
+        for _, pos, _ in passes:
+            cos, sin = ops_ref.rope_tables(self.D, self.theta, int(pos.max()) + 1, torch.float32, self.rope_factor)
+            ropes.append((cos[pos.long()], sin[pos.long()]))
+        for l in range(self.L):
+            for i, (_, _, seq) in enumerate(passes):
+                keep = self._last_rows(seq) if (i == 0 and l == self.L - 1) else None  # prefill: last_only
+                xs[i], rs[i] = self._layer(l, xs[i], rs[i], ropes[i][0], ropes[i][1], seq, state, keep)
+            self._w = {k: v for k, v in self._w.items() if not k.startswith(f"model.layers.{l}.")}
+            if l not in keep_cache_layers:
+                for b in range(B):
+                    state[b][l] = None
+        if self.L == 0:
+            xs[0] = xs[0][self._last_rows(passes[0][2])]
+        cu = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        cu_q = np.arange(B + 1, dtype=np.int64)
+        steps = []
+        for i in range(n_steps):
+            hfin, _ = ops_ref.rmsnorm_residual(xs[i], rs[i], self._vec("model.norm.weight"), self.eps)
+            logits = hfin @ self._lin("lm_head")
+            tok, lp = ops_ref.greedy(logits)
+            cu = cu + cu_q
+            steps.append({"logits": logits, "token_ids": tok.clone(), "logprobs": lp,
+                          "slot_indices": torch.from_numpy(cu[1:] - 1)})
+        return steps
 
     def generate_greedy(self, prompts: List[List[int]], new_tokens: int, forced: Optional[List[List[int]]] = None):
         """Prefill + greedy decode, the loop of FlashCausalLM.generate_token / CausalLM.generate_token

@@ -40,20 +40,28 @@ def gptq_pack(intweight: np.ndarray, zeros_true: np.ndarray, bits: int = 4):
 def gptq_dequant(qweight, qzeros, scales, g_idx: Optional[np.ndarray], groupsize: int) -> torch.Tensor:
     """W[k,n] = (q[k,n] - (z[g(k),n] + 1)) * s[g(k),n] in fp32 — the unpack of matmul_248_kernel
     (utils/gptq/quant_linear.py:130-138,159-192; note zeros+1 is NOT masked back to 4 bits)."""
-    qw = np.asarray(qweight).astype(np.uint32)
-    qz = np.asarray(qzeros).astype(np.uint32)
+    # (torch integer ops on all host cores: the numpy form of rounds 1-3 took 5 s for one 4096 x 22016 matrix, which made a
+    # 32-layer oracle at width unaffordable; same integer unpack, same fp32 expression)
+    qw = torch.from_numpy(np.ascontiguousarray(np.asarray(qweight))).to(torch.int32)
+    qz = torch.from_numpy(np.ascontiguousarray(np.asarray(qzeros))).to(torch.int32)
     K = qw.shape[0] * 8
     N = qw.shape[1]
-    shifts = (np.arange(K) % 8) * 4
-    q = (qw[np.arange(K) // 8, :] >> shifts[:, None]) & 15  # [K,N]
-    zshift = (np.arange(N) % 8) * 4
-    z = ((qz[:, np.arange(N) // 8] >> zshift[None, :]) & 15) + 1  # [G,N]
+    sh = (torch.arange(8, dtype=torch.int32) * 4)
+    q = (qw.unsqueeze(1) >> sh.view(1, 8, 1)).bitwise_and_(15).view(K, N)  # row k = pack k // 8, nibble k % 8
+    z = ((qz.unsqueeze(2) >> sh.view(1, 1, 8)) & 15).reshape(qz.shape[0], N) + 1  # column n = pack n // 8, nibble n % 8
     if g_idx is None:
-        g_idx = np.arange(K) // groupsize
-    g_idx = np.asarray(g_idx).astype(np.int64)
-    s = torch.as_tensor(np.asarray(scales, dtype=np.float32) if not torch.is_tensor(scales) else
-                        scales.float().cpu().numpy())
-    w = (torch.from_numpy(q.astype(np.float32)) - torch.from_numpy(z.astype(np.float32))[g_idx]) * s[g_idx]
+        gi = torch.arange(K, dtype=torch.int64) // groupsize
+    else:
+        gi = torch.from_numpy(np.asarray(g_idx).astype(np.int64))
+    s = scales.float().cpu() if torch.is_tensor(scales) else torch.from_numpy(np.asarray(scales, dtype=np.float32))
+    if g_idx is None and K % groupsize == 0 and K // groupsize == z.shape[0]:
+        G = z.shape[0]
+        w = q.view(G, groupsize, N).float()  # in place from here on (fresh 100-MB temporaries cost more than the arithmetic)
+        w.sub_(z.float().view(G, 1, N)).mul_(s.view(G, 1, N))
+        w = w.view(K, N)
+    else:
+        w = q.float()
+        w.sub_(z.float()[gi]).mul_(s[gi])
     return w  # [K,N] fp32
 
 

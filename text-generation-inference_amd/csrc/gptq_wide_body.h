@@ -180,8 +180,12 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
             const bool roth = nt / per < a.rH + a.rHkv;
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
+#if defined(WIDE_ABL) && WIDE_ABL == 4
+                rcos[t][j] = (f16)0.5f, rsin[t][j] = (f16)0.25f;
+#else
                 rcos[t][j] = roth ? a.cosb[(int64_t)rpos[j] * (a.rD >> 1) + dr] : (f16)1.f;
                 rsin[t][j] = roth ? a.sinb[(int64_t)rpos[j] * (a.rD >> 1) + dr] : (f16)0.f;
+#endif
             }
         }
     }
@@ -236,9 +240,18 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
                 const f16 oh = (f16)o;
                 if (m < mrows) {
                     if (head < a.rH) {
+#if !defined(WIDE_ABL) || WIDE_ABL != 3
                         a.out[(int64_t)m * a.ldo + col] = oh;
+#endif
                     } else {
+#if defined(WIDE_ABL) && (WIDE_ABL == 2 || WIDE_ABL == 3)
+                        if (oh == (f16)12345.f) a.out[0] = oh;
+                        continue;
+#endif
                         const int page = rslot[j] >> 5, tok = rslot[j] & 31;
+#if defined(WIDE_ABL) && WIDE_ABL == 1
+                        if (!roth) { if (oh == (f16)12345.f) a.out[0] = oh; continue; }
+#endif
                         if (roth)
                             a.kpool[((int64_t)page * a.rHkv + (head - a.rH)) * 32 * a.rD + k_off(tok, d, a.rD)] = oh;
                         else
