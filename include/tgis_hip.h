@@ -96,16 +96,16 @@ int64_t tgis_gptq_gemm_fused_rows(int64_t K, int64_t groups, int act_order, int 
 int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
 
 /* Activation layout between the decode step's own kernels (round 4).  A leading dimension of TGIS_LD_FRAGMENTS says that a
- * [M <= 32, K] f16 activation (K % 64 == 0; the buffer holds 32 * K elements whatever M is) is stored in the order the MFMA
- * reads it — [k64-step][i = k/8 % 4][lane = 32 (k/32 % 2) + row][k % 8], i.e. element (m, k) at
- * ((k/64 * 4 + k/8 % 4) * 64 + 32 (k/32 % 2) + m) * 8 + k % 8 — instead of row-major.  Producers that can write it:
+ * [M <= 64, K] f16 activation (K % 64 == 0; the buffer holds ceil(M / 32) * 32 * K elements) is stored in the order the MFMA
+ * reads it — [row block m/32][k64-step][i = k/8 % 4][lane = 32 (k/32 % 2) + m % 32][k % 8], i.e. element (m, k) at
+ * (m/32) * 32 K + ((k/64 * 4 + k/8 % 4) * 64 + 32 (k/32 % 2) + m % 32) * 8 + k % 8 — instead of row-major.  Producers that can write it:
  * tgis_rmsnorm_residual[_partial] (ldy), tgis_attn_paged (ld_out), tgis_gptq_gemm_f16 with act = 2 (ldo).  Consumers:
  * tgis_gptq_gemm_f16, tgis_gptq_gemm_f16_partial, tgis_gptq_gemm_rope_f16 (ldx), which then run the kernel of
  * csrc/gptq_wide_body.h: each k64-step of the activation is four contiguous KiB straight into the A operand, no LDS staging
  * (7B shapes, 32 rows: qkv + rope 16.9 -> 12 us, o 6.0 -> 5.3, gate_up 16.8 -> 14.4, down 10.5 -> 9.2).  Same arithmetic as
  * the row-major path ((q - z) * s rounded to f16 once, fp32 accumulation); only the summation order over k differs.
  * tgis_gptq_fragments_ok: 1 if the GEMM (act 0, 2, or 3 = the rope epilogue) takes such an activation and is expected to be
- * faster with it (1 <= M <= 32, no act-order, groups of 64 * 2^n rows; act 2 / 3 additionally >= 128 workgroups). */
+ * faster with it (1 <= M <= 64, no act-order, groups of 64 * 2^n rows; act 2 / 3 additionally >= 128 workgroups). */
 #define TGIS_LD_FRAGMENTS ((int64_t)-32)
 int tgis_gptq_fragments_ok(int64_t M, int64_t K, int64_t N, int64_t groups, int act_order, int act);
 
@@ -189,7 +189,7 @@ int tgis_dense_gemm_partial(const void* x, int64_t ldx, const void* prepared, in
  *      custom_modeling/flash_llama_modeling.py:132-152, utils/layers.py:376-396) ---------------- */
 /* res_out = x (+ residual); y = res_out * rsqrt(mean(res_out^2) + eps) * weight.
  * residual may be NULL (first layer).  res_out may alias residual or x.  fp32 statistics.
- * ldy: 0 or hidden (y row-major), or TGIS_LD_FRAGMENTS (rows <= 32, hidden % 64 == 0: y feeds an int4 GEMM of the decode
+ * ldy: 0 or hidden (y row-major), or TGIS_LD_FRAGMENTS (rows <= 64, hidden % 64 == 0: y feeds an int4 GEMM of the decode
  * step, see TGIS_LD_FRAGMENTS above). */
 int tgis_rmsnorm_residual(const void* x, const void* residual, const void* weight, void* y, int64_t ldy,
                           void* res_out, int64_t rows, int64_t hidden, float eps, int dtype,
@@ -244,7 +244,7 @@ int tgis_attn_num_splits(int64_t B, int Hkv, int H, int64_t max_q_len, int64_t m
 int64_t tgis_attn_workspace_bytes(int64_t total_q_tokens, int H, int Hkv, int D, int num_splits);
 /* Causal softmax(q k^T * scale) v over the paged cache.
  *   q: [total_q, H, D] with token stride ld_q (elements); out: [total_q, H*D] contiguous (ld_out = 0 or
- *   H*D), or — decode, B <= 32 — in fragment order for the o_proj GEMM (ld_out = TGIS_LD_FRAGMENTS).
+ *   H*D), or — decode, B <= 64 — in fragment order for the o_proj GEMM (ld_out = TGIS_LD_FRAGMENTS).
  *   cu_seqlens_q [B+1] int32: q token offsets per sequence (decode: arange).
  *   ctx_lens [B] int32: tokens of each sequence present in the cache INCLUDING the q tokens.
  *   block_tables [B, max_pages] int32: page ids.  q token i of sequence b sits at position

@@ -29,14 +29,14 @@ def _weight(nat, dev, K, N, gs, seed, **kw):
 
 def test_fragment_order_round_trip_and_offsets(nat, gpu_device):
     """FragAct.from_rows / to_rows are inverse, and element (m, k) sits where include/tgis_hip.h says."""
-    M, K = 7, 256
-    x = torch.arange(M * K, dtype=torch.float32).view(M, K).half().to(gpu_device)
-    f = nat.FragAct.from_rows(x)
-    assert torch.equal(f.to_rows(), x)
-    buf = f.buf.cpu()
-    for m, k in ((0, 0), (3, 9), (6, 63), (5, 64 + 37), (2, 255)):
-        off = ((k // 64 * 4 + k // 8 % 4) * 64 + 32 * (k // 32 % 2) + m) * 8 + k % 8
-        assert buf[off] == x[m, k].cpu()
+    for M, K in ((7, 256), (45, 128)):
+        x = (torch.arange(M * K, dtype=torch.float32) % 2039).view(M, K).half().to(gpu_device)
+        f = nat.FragAct.from_rows(x)
+        assert torch.equal(f.to_rows(), x)
+        buf = f.buf.cpu()
+        for m, k in ((0, 0), (3, 9), (6, 63), (5, 64 + 37), (2, K - 1), (M - 1, 70)):
+            off = (m // 32) * 32 * K + ((k // 64 * 4 + k // 8 % 4) * 64 + 32 * (k // 32 % 2) + m % 32) * 8 + k % 8
+            assert buf[off] == x[m, k].cpu()
 
 
 @pytest.mark.parametrize("M,K,N,gs", [
@@ -49,6 +49,10 @@ def test_fragment_order_round_trip_and_offsets(nat, gpu_device):
     (32, 1408, 4096, 64),     # a row-parallel shard: 22 steps
     (5, 64, 64, 64),          # one k64-step: seven of the eight waves have nothing to do
     (32, 8192, 1024, 128),    # 70B shard shapes
+    (64, 4096, 4096, 128),    # two row blocks: every dequantised fragment feeds two MFMAs
+    (40, 11008, 4096, 128),   # ragged second row block
+    (33, 1024, 160, 64),
+    (64, 8192, 7168, 128),    # 70B gate_up shard at TP = 8
 ])
 def test_fragment_gemm_matches_the_oracle_and_the_row_major_launch(nat, gpu_device, M, K, N, gs):
     (qw, qz, sc, gi), w = _weight(nat, gpu_device, K, N, gs, seed=K + N + M)
@@ -60,7 +64,9 @@ def test_fragment_gemm_matches_the_oracle_and_the_row_major_launch(nat, gpu_devi
     ws = nat.Workspace(w.workspace_bytes(M), gpu_device)
     xd = x.to(gpu_device)
     xf = nat.FragAct.from_rows(xd)
-    xf.buf.view(-1, 64, 8)[:, M:32].fill_(float("nan")) if M < 32 else None  # rows past M must not matter (lanes M..31)
+    if M % 32:  # rows past M must not matter: poison them (lanes M % 32 .. 31 of both halves in the last row block)
+        last = xf.buf.view((M + 31) // 32, -1, 2, 32, 8)[-1]
+        last[:, :, M % 32:].fill_(float("nan"))
     got = nat.gptq_gemm(xf, w, ws, bias=bias.to(gpu_device))
     row = nat.gptq_gemm(xd, w, ws, bias=bias.to(gpu_device))
     tol = dict(rtol=2e-3, atol=2e-3 * float(want.abs().mean()) + 1e-4)
@@ -71,12 +77,13 @@ def test_fragment_gemm_matches_the_oracle_and_the_row_major_launch(nat, gpu_devi
     assert torch.equal(got, nat.gptq_gemm(xf, w, ws, bias=bias.to(gpu_device))), "not deterministic"
     # deferred reduce: the slabs' sum (+ bias) rounds to the same f16 tensor
     p = nat.gptq_gemm_partial(xf, w, bias=bias.to(gpu_device))
-    sl = p.slabs[:p.S * 32 * p.ld].view(p.S, 32, p.ld)[:, :M, :N].sum(0) + bias.to(gpu_device).float()
+    rb = (M + 31) // 32
+    sl = p.slabs[:rb * p.S * 32 * p.ld].view(rb, p.S, 32, p.ld).sum(1).reshape(rb * 32, p.ld)[:M, :N] + bias.to(gpu_device).float()
     dd = (sl.half().float() - got.float()).abs()
     assert float(dd.max()) <= 2.0 ** -9 * float(want.abs().max()) + 1e-3
 
 
-@pytest.mark.parametrize("M,K,I", [(32, 4096, 11008), (9, 1024, 1408), (32, 2048, 5632)])
+@pytest.mark.parametrize("M,K,I", [(32, 4096, 11008), (9, 1024, 1408), (32, 2048, 5632), (64, 4096, 11008), (45, 8192, 3584)])
 def test_fragment_gemm_silu_epilogue_and_fragment_output(nat, gpu_device, M, K, I):
     """gate_up on the interleaved image with a fragment-order operand: row-major and fragment-order outputs hold the same
     bits, and equal the row-major launch up to summation order."""
@@ -99,7 +106,8 @@ def test_fragment_gemm_silu_epilogue_and_fragment_output(nat, gpu_device, M, K, 
 
 
 @pytest.mark.parametrize("H,Hkv,D,K,B,gs,bias", [(32, 32, 128, 4096, 32, 128, False), (8, 8, 128, 4096, 7, 128, True),
-                                                  (32, 4, 64, 2048, 16, 64, False), (64, 8, 128, 1024, 1, 128, False)])
+                                                  (32, 4, 64, 2048, 16, 64, False), (64, 8, 128, 1024, 1, 128, False),
+                                                  (32, 32, 128, 4096, 64, 128, False), (8, 1, 128, 8192, 50, 128, True)])
 def test_fragment_gemm_rope_epilogue(nat, gpu_device, H, Hkv, D, K, B, gs, bias):
     """tgis_gptq_gemm_rope_f16 with a fragment-order operand against the same launch on the row-major operand: q and the
     cache pages agree up to the summation order of the two k partitions."""
@@ -125,14 +133,15 @@ def test_fragment_gemm_rope_epilogue(nat, gpu_device, H, Hkv, D, K, B, gs, bias)
     assert pools[2].abs().sum() > 0 and pools[3].abs().sum() > 0
 
 
-@pytest.mark.parametrize("rows,hidden,partial", [(32, 4096, True), (5, 4096, False), (17, 2048, True), (1, 256, False)])
+@pytest.mark.parametrize("rows,hidden,partial", [(32, 4096, True), (5, 4096, False), (17, 2048, True), (1, 256, False),
+                                                 (64, 8192, True), (47, 4096, False)])
 def test_rmsnorm_writes_the_same_bits_in_fragment_order(nat, gpu_device, rows, hidden, partial):
     g = torch.Generator().manual_seed(rows + hidden)
     res = (torch.randn(rows, hidden, generator=g)).half().to(gpu_device)
     wn = (1 + 0.1 * torch.randn(hidden, generator=g)).half().to(gpu_device)
     if partial:
         S, ld = 3, hidden
-        slabs = torch.randn(S, 32, ld, generator=g).to(gpu_device)
+        slabs = torch.randn((rows + 31) // 32, S, 32, ld, generator=g).to(gpu_device)
         src = lambda: nat.Partial(slabs.reshape(-1), S, ld, rows, hidden, None)  # noqa: E731
     else:
         x = torch.randn(rows, hidden, generator=g).half().to(gpu_device)
@@ -142,7 +151,8 @@ def test_rmsnorm_writes_the_same_bits_in_fragment_order(nat, gpu_device, rows, h
     assert isinstance(y1, nat.FragAct) and torch.equal(y1.to_rows(), y0) and torch.equal(r0, r1)
 
 
-@pytest.mark.parametrize("B,H,Hkv,D,ctx", [(32, 32, 32, 128, 300), (16, 32, 4, 64, 512), (3, 32, 8, 128, 1500), (4, 48, 1, 128, 700)])
+@pytest.mark.parametrize("B,H,Hkv,D,ctx", [(32, 32, 32, 128, 300), (16, 32, 4, 64, 512), (3, 32, 8, 128, 1500), (4, 48, 1, 128, 700),
+                                           (64, 8, 1, 128, 600), (50, 32, 32, 128, 100)])
 def test_decode_attention_writes_the_same_bits_in_fragment_order(nat, gpu_device, B, H, Hkv, D, ctx):
     """tgis_attn_paged with ld_out = TGIS_LD_FRAGMENTS (every combine path: in-block, in-launch merge, combine launch)."""
     g = torch.Generator().manual_seed(B + H + ctx)

@@ -685,8 +685,8 @@ static int attn_paged_impl(const void* q, int64_t ld_q, const void* k_pool, cons
     TGIS_CHECK_ARG(max_q_len > 0 && max_pages > 0 && num_splits >= 1, "tgis_attn_paged: bad launch bounds");
     TGIS_CHECK_ARG(num_splits == 1 || max_q_len == 1, "tgis_attn_paged: key splits are for decode (max_q_len == 1)");
     TGIS_CHECK_ARG(ld_out == 0 || ld_out == (int64_t)H * D ||
-                       (ld_out == TGIS_LD_FRAGMENTS && max_q_len == 1 && B <= 32 && ((int64_t)H * D) % 64 == 0),
-                   "tgis_attn_paged: out is [tokens, H * D] contiguous (ld_out = 0 or H * D), or — decode, <= 32 sequences — in "
+                       (ld_out == TGIS_LD_FRAGMENTS && max_q_len == 1 && B <= 64 && ((int64_t)H * D) % 64 == 0),
+                   "tgis_attn_paged: out is [tokens, H * D] contiguous (ld_out = 0 or H * D), or — decode, <= 64 sequences — in "
                    "fragment order (ld_out = TGIS_LD_FRAGMENTS)");
     (void)max_ctx;
     if (B == 0) return TGIS_OK;

@@ -108,10 +108,10 @@ __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
 
 // Decode batches of up to 32 rows whose activation is in fragment order (gptq_wide_body.h).  8 waves; CT = 4 holds 2 waves
 // per SIMD (one block per CU), CT = 2 / 3 leave room for more.
-template <int CT, int ACT, bool OUTF>
+template <int CT, int ACT, bool OUTF, int MR>
 __global__ __launch_bounds__(64 * gptq::WIDE_WK) void gptq_wide_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    gptq::gptq_wide_unit<CT, ACT, OUTF>(a, smem);
+    gptq::gptq_wide_unit<CT, ACT, OUTF, MR>(a, smem);
 }
 
 // ---- "tall" kernel: 64 < M (decode batches beyond 32 rows, add-on prefills of up to a few thousand tokens) --------
@@ -604,7 +604,7 @@ extern "C" int64_t tgis_gptq_gemm_fused_rows(int64_t K, int64_t groups, int act_
 extern "C" int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N) {
     GemmPlan pl = plan_gemm(K, N, 0, M);
     int64_t need = 4096 + slab_bytes(M, N, pl.S);
-    if (M <= 32 && K % 64 == 0) need = std::max(need, 4096 + slab_bytes(M, N, gptq::plan_wide(K, N, 0).S));
+    if (M <= 64 && K % 64 == 0) need = std::max(need, 4096 + slab_bytes(M, N, gptq::plan_wide(K, N, 0).S));
     if (M >= tall_min_m() && K % 64 == 0) need = std::max(need, 4096 + tall_slab_bytes(M, N, plan_tall(M, K, N, 0).S));
     return need;
 }
@@ -652,17 +652,21 @@ struct RopeEpi {
     int H, Hkv, D;
 };
 
-template <int CT, int ACT, bool OUTF>
-static int launch_wide_one(dim3 grid, hipStream_t st, const GemmArgs& a) {
+template <int CT, int ACT, bool OUTF, int MR>
+static int launch_wide_mr(dim3 grid, hipStream_t st, const GemmArgs& a) {
     constexpr size_t lds = (size_t)gptq::WIDE_WK * CT * 4096;
     static bool attr_done = false;
     if (!attr_done) {
-        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_wide_kernel<CT, ACT, OUTF>,
+        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_wide_kernel<CT, ACT, OUTF, MR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gptq_wide_kernel<CT, ACT, OUTF>), grid, dim3(64 * gptq::WIDE_WK), lds, st, a);
+    hipLaunchKernelGGL((gptq_wide_kernel<CT, ACT, OUTF, MR>), grid, dim3(64 * gptq::WIDE_WK), lds, st, a);
     return TGIS_OK;
+}
+template <int CT, int ACT, bool OUTF>
+static int launch_wide_one(dim3 grid, hipStream_t st, const GemmArgs& a) {
+    return a.M > 32 ? launch_wide_mr<CT, ACT, OUTF, 2>(grid, st, a) : launch_wide_mr<CT, ACT, OUTF, 1>(grid, st, a);
 }
 
 static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const void* bias, const int32_t* perm,
@@ -733,7 +737,7 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
         TGIS_CHECK_LAUNCH();
         if (!partial && pl.S > 1) {
             const int NP = (int)p.NT * 32;
-            dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 4), 256), 1);
+            dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 4), 256), (unsigned)cdiv64(M, 32));
             hipLaunchKernelGGL(splitk_reduce_f16_kernel, rgrid, dim3(256), 0, st, a.slabs, a.bias, a.out, a.ldo, a.M, a.N,
                                NP, a.S);
             TGIS_CHECK_LAUNCH();
@@ -814,7 +818,7 @@ static int check_gemm_args(const void* x, int64_t ldx, const void* prepared, int
     TGIS_CHECK_ARG(act != 2 || N % 32 == 0, "tgis_gptq_gemm: act=2 needs N/2 to be a multiple of 16");
     if (ldx == TGIS_LD_FRAGMENTS) {
         TGIS_CHECK_ARG(((uintptr_t)x % 16) == 0 && gptq::wide_serves(M, K, N, groups, false) && act != 1,
-                       "tgis_gptq_gemm: an activation in fragment order needs 1 <= M <= 32, K %% 64 == 0, groups of 64 * 2^n "
+                       "tgis_gptq_gemm: an activation in fragment order needs 1 <= M <= 64, K %% 64 == 0, groups of 64 * 2^n "
                        "rows and act 0 or 2 (M=%ld K=%ld N=%ld groups=%ld act=%d)", (long)M, (long)K, (long)N, (long)groups, act);
         return TGIS_OK;
     }
@@ -1073,7 +1077,7 @@ extern "C" int tgis_gptq_norm_qkv_rope_f16(const tgis_norm_in* norm, const void*
 extern "C" int64_t tgis_gptq_gemm_partial_bytes(int64_t M, int64_t K, int64_t N) {
     GemmPlan pl = plan_gemm(K, N, 0, M);
     int64_t need = cdiv64(std::max<int64_t>(M, 1), 64) * 2 * pl.S * 32 * cdiv64(N, 32) * 32 * 4;
-    if (M <= 32 && K % 64 == 0)  // the fragment-order kernel's plan may split further
+    if (M <= 64 && K % 64 == 0)  // the fragment-order kernel's plan may split further
         need = std::max<int64_t>(need, (int64_t)2 * gptq::plan_wide(K, N, 0).S * 32 * cdiv64(N, 32) * 32 * 4);
     if (M >= tall_min_m() && K % 64 == 0) need = std::max(need, tall_slab_bytes(M, N, plan_tall(M, K, N, 0).S));
     return need;
@@ -1086,6 +1090,8 @@ extern "C" int tgis_gptq_fragments_ok(int64_t M, int64_t K, int64_t N, int64_t g
     if (act != 0 && act != 2 && act != 3) return 0;
     static const bool off = getenv("TGIS_GPTQ_FRAGMENTS") && atoi(getenv("TGIS_GPTQ_FRAGMENTS")) == 0;
     if (off) return 0;
+    static const int64_t max_rows = getenv("TGIS_GPTQ_FRAGMENTS_MAX_ROWS") ? atoll(getenv("TGIS_GPTQ_FRAGMENTS_MAX_ROWS")) : 64;
+    if (M > max_rows) return 0;
     static const int64_t min_blocks = getenv("TGIS_ROPE_MIN_BLOCKS") ? atoll(getenv("TGIS_ROPE_MIN_BLOCKS")) : 128;
     if ((act == 2 || act == 3) && gptq::wide_blocks(K, N, act) < min_blocks) return 0;
     return 1;

@@ -29,10 +29,10 @@ struct WidePlan {
     int CT, S;  // column tiles per wave (= per block), global k splits
 };
 
-// Does the fragment-order kernel serve this GEMM at all?  (<= 32 rows, whole k64-steps, one {scale, zero} per k64-step and
+// Does the fragment-order kernel serve this GEMM at all?  (<= 64 rows, whole k64-steps, one {scale, zero} per k64-step and
 // column, no act-order permutation.)
 static inline bool wide_serves(int64_t M, int64_t K, int64_t N, int64_t groups, bool act_order) {
-    if (M < 1 || M > 32 || act_order || K % 64 || N % 32 || groups < 1 || K % groups) return false;
+    if (M < 1 || M > 64 || act_order || K % 64 || N % 32 || groups < 1 || K % groups) return false;
     const int64_t gs = K / groups;
     if (groups == 1) return true;
     if (gs % 64) return false;
@@ -67,7 +67,9 @@ static inline int64_t wide_blocks(int64_t K, int64_t N, int act) {
 }
 
 // OUTF: the act = 2 output (the operand of the down projection) leaves in fragment order as well.
-template <int CT, int ACT, bool OUTF>
+// MR = 32-row blocks of the activation (1: M <= 32; 2: M <= 64 — every dequantised B fragment then feeds two MFMAs, the
+// "two tiles per wave on one activation" of the 64-row passes, with the activation in registers instead of LDS).
+template <int CT, int ACT, bool OUTF, int MR>
 __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char* smem) {
     constexpr int WK = WIDE_WK, DEPTH = WIDE_DEPTH, NR = 16 / WK;
     const int lane = threadIdx.x & 63;
@@ -78,7 +80,7 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
     const int sb = split * sp_len, se = min(steps, sb + sp_len);
     const int len = max(se - sb, 0);
     const int s0 = sb + (len * wk) / WK, s1 = sb + (len * (wk + 1)) / WK;  // this wave's k64-steps (may be empty)
-    const int mrows = a.M;  // 1..32
+    const int mrows = a.M;  // 1 .. 32 MR
 
     const char* wt[CT];
     const char* st[CT];
@@ -91,10 +93,11 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
     const uint32_t woff = lane * 16, szoff = (lane & 31) * 4;
     const int sclamp = max(s1 - 1, s0);  // loads past the wave's steps re-read its last one (a cache hit), never consumed
     const char* xb = reinterpret_cast<const char*>(a.x);
+    const int64_t xblk = (int64_t)a.K * 64;  // bytes between the 32-row blocks of the activation
 
     u32x4 wq[DEPTH][CT];
     uint32_t sz[DEPTH][CT];
-    f16x8 xa[DEPTH][4];
+    f16x8 xa[DEPTH][MR][4];
     auto load_step = [&](int d, int step) {
         const int sc = min(step, sclamp);
         const int g = min(sc >> a.spg_shift, a.G - 1);
@@ -110,30 +113,41 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
             PIN_SGPR(p);
             wq[d][t] = __builtin_nontemporal_load((const GLOBAL_AS u32x4*)(p + woff));
         }
-        const char* p = xb + (int64_t)sc * 4096;  // fragment order: four contiguous KiB per k64-step
-        PIN_SGPR(p);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xa[d][i] = *(const GLOBAL_AS f16x8*)(p + woff + i * 1024);
+        for (int mr = 0; mr < MR; ++mr) {
+            const char* p = xb + mr * xblk + (int64_t)sc * 4096;  // fragment order: four contiguous KiB per k64-step
+            PIN_SGPR(p);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xa[d][mr][i] = *(const GLOBAL_AS f16x8*)(p + woff + i * 1024);
+        }
     };
 
-    // ACT 3: cache slot and rotary position of the two rows this wave finishes
-    int32_t rpos[ACT == 3 ? NR : 1], rslot[ACT == 3 ? NR : 1];
+    // the rows this wave finishes: accumulator registers [wk NR, (wk + 1) NR) of every tile and row block
+    auto row_of = [&](int mr, int j) {
+        const int r = wk * NR + j;
+        return mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    };
+    // ACT 3: their cache slots and rotary positions
+    int32_t rpos[ACT == 3 ? MR : 1][ACT == 3 ? NR : 1], rslot[ACT == 3 ? MR : 1][ACT == 3 ? NR : 1];
     if (ACT == 3) {
 #pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const int r = wk * NR + j;
-            const int m = min((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), mrows - 1);
-            rpos[j] = a.positions[m];
-            rslot[j] = a.slots[m];
-        }
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int m = min(row_of(mr, j), mrows - 1);
+                rpos[mr][j] = a.positions[m];
+                rslot[mr][j] = a.slots[m];
+            }
     }
 
     uint32_t EXr = 0x64006400u, M0r = 0x000F000Fu, M1r = 0x00F000F0u;
     asm volatile("" : "+v"(EXr));
     asm volatile("" : "+s"(M0r), "+s"(M1r));
-    f32x16 acc[CT];
+    f32x16 acc[MR][CT];
 #pragma unroll
-    for (int t = 0; t < CT; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[mr][t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) load_step(d, s0 + d);
@@ -148,7 +162,8 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f16x8 b = dequant8(wq[d][t][i], zc, zd, sc, EXr, M0r, M1r);
-                acc[t] = mfma32(xa[d][i], b, acc[t]);
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) acc[mr][t] = mfma32(xa[d][mr][i], b, acc[mr][t]);
             }
         }
     };
@@ -169,7 +184,7 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
         if (s + d < s1) consume(d);
 
     // ACT 3: the finishing rows' cos / sin entries are requested before the exchange (their positions came in at entry)
-    f16 rcos[ACT == 3 ? CT : 1][ACT == 3 ? NR : 1], rsin[ACT == 3 ? CT : 1][ACT == 3 ? NR : 1];
+    f16 rcos[ACT == 3 ? MR : 1][ACT == 3 ? CT : 1][ACT == 3 ? NR : 1], rsin[ACT == 3 ? MR : 1][ACT == 3 ? CT : 1][ACT == 3 ? NR : 1];
     if (ACT == 3) {
         const int per = a.rD >> 5;
 #pragma unroll
@@ -179,125 +194,115 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
             const int dr = 16 * tt + (lane & 15);
             const bool roth = nt / per < a.rH + a.rHkv;
 #pragma unroll
-            for (int j = 0; j < NR; ++j) {
-#if defined(WIDE_ABL) && WIDE_ABL == 4
-                rcos[t][j] = (f16)0.5f, rsin[t][j] = (f16)0.25f;
-#else
-                rcos[t][j] = roth ? a.cosb[(int64_t)rpos[j] * (a.rD >> 1) + dr] : (f16)1.f;
-                rsin[t][j] = roth ? a.sinb[(int64_t)rpos[j] * (a.rD >> 1) + dr] : (f16)0.f;
-#endif
-            }
-        }
-    }
-
-    // ---- k-part sum through LDS: [k-part][tile][register][lane], then wave wk sums registers [wk NR, (wk + 1) NR) ----
-    float* red = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int t = 0; t < CT; ++t) {
-        float* dst = red + ((wk * CT + t) << 10) + lane;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dst[r << 6] = acc[t][r];
-    }
-    __syncthreads();
-    float fin[CT][NR];
-#pragma unroll
-    for (int t = 0; t < CT; ++t) {
-#pragma unroll
-        for (int k2 = 0; k2 < WK; ++k2) {
-            const float* src = red + ((k2 * CT + t) << 10) + ((wk * NR) << 6) + lane;
-#pragma unroll
-            for (int j = 0; j < NR; ++j) fin[t][j] = k2 == 0 ? src[j << 6] : fin[t][j] + src[j << 6];
-        }
-    }
-
-    const int c = lane & 31;
-    auto row_of = [&](int j) {
-        const int r = wk * NR + j;
-        return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    };
-#pragma unroll
-    for (int t = 0; t < CT; ++t) {
-        const int nt = cg * CT + t;
-        if (nt >= a.NT) break;
-        if (ACT == 3) {
-            // rope image: see gptq_gemm_body.h (the same epilogue on the same image)
-            const int per = a.rD >> 5;
-            const int head = nt / per, tt = nt - head * per;
-            const bool roth = head < a.rH + a.rHkv;
-            const int d = roth ? ((c < 16) ? 16 * tt + c : (a.rD >> 1) + 16 * tt + (c - 16)) : 32 * tt + c;
-            const int col = head * a.rD + d;
-            const float bv = a.bias ? (float)a.bias[col] : 0.f;
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                const int m = row_of(j);
-                const float mine = (float)(f16)(fin[t][j] + bv);
-                float o = mine;
-                if (roth) {
-                    const float other = __shfl_xor(mine, 16, 64);
-                    const float cf = (float)rcos[t][j], sf = (float)rsin[t][j];
-                    o = (c < 16) ? mine * cf - other * sf : other * sf + mine * cf;
-                }
-                const f16 oh = (f16)o;
-                if (m < mrows) {
-                    if (head < a.rH) {
-#if !defined(WIDE_ABL) || WIDE_ABL != 3
-                        a.out[(int64_t)m * a.ldo + col] = oh;
-#endif
-                    } else {
-#if defined(WIDE_ABL) && (WIDE_ABL == 2 || WIDE_ABL == 3)
-                        if (oh == (f16)12345.f) a.out[0] = oh;
-                        continue;
-#endif
-                        const int page = rslot[j] >> 5, tok = rslot[j] & 31;
-#if defined(WIDE_ABL) && WIDE_ABL == 1
-                        if (!roth) { if (oh == (f16)12345.f) a.out[0] = oh; continue; }
-#endif
-                        if (roth)
-                            a.kpool[((int64_t)page * a.rHkv + (head - a.rH)) * 32 * a.rD + k_off(tok, d, a.rD)] = oh;
-                        else
-                            a.vpool[((int64_t)page * a.rHkv + (head - a.rH - a.rHkv)) * 32 * a.rD + (int64_t)d * 32 +
-                                    v_col(tok)] = oh;
-                    }
-                }
-            }
-            continue;
-        }
-        const int n = nt * 32 + c;
-        if (ACT == 2) {
-            // interleaved gate / up image: lanes c < 16 hold gate column j2, lanes c + 16 the matching up column
-            const int half = a.N >> 1;
-            const int j2 = nt * 16 + (c & 15);
-            const int nsrc = (c < 16) ? j2 : half + j2;
-            const float bv = (a.bias && j2 < half) ? (float)a.bias[nsrc] : 0.f;
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                const float mine = (float)(f16)(fin[t][j] + bv);
-                const float other = __shfl_xor(mine, 16, 64);
-                const int m = row_of(j);
-                if (c < 16 && j2 < half && m < mrows) {
-                    const float sl = mine / (1.f + __expf(-mine));
-                    const f16 o = (f16)((float)(f16)sl * other);
-                    if (OUTF)
-                        a.out[xf_off(m, j2, half)] = o;
-                    else
-                        a.out[(int64_t)m * a.ldo + j2] = o;
-                }
-            }
-            continue;
-        }
-        if (a.S == 1 && !a.partial) {
-            const float bv = (a.bias && n < a.N) ? (float)a.bias[n] : 0.f;
-            if (n < a.N) {
+            for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
-                    const int m = row_of(j);
-                    if (m < mrows) a.out[(int64_t)m * a.ldo + n] = (f16)(fin[t][j] + bv);
+                    rcos[mr][t][j] = roth ? a.cosb[(int64_t)rpos[mr][j] * (a.rD >> 1) + dr] : (f16)1.f;
+                    rsin[mr][t][j] = roth ? a.sinb[(int64_t)rpos[mr][j] * (a.rD >> 1) + dr] : (f16)0.f;
                 }
-            }
-        } else {
-            float* sl = a.slabs + ((int64_t)split * 32) * (a.NT * 32) + n;
+        }
+    }
+
+    // ---- k-part sum through LDS, one 32-row block at a time: [k-part][tile][register][lane] (every access 64 consecutive
+    // words), then wave wk sums registers [wk NR, (wk + 1) NR) of every tile in the fixed order of the k-parts ----
+    float* red = reinterpret_cast<float*>(smem);
+    const int c = lane & 31;
 #pragma unroll
-            for (int j = 0; j < NR; ++j) sl[(int64_t)row_of(j) * (a.NT * 32)] = fin[t][j];
+    for (int mr = 0; mr < MR; ++mr) {
+        if (mr > 0) __syncthreads();  // the previous row block's sums have been read
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            float* dst = red + ((wk * CT + t) << 10) + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r << 6] = acc[mr][t][r];
+        }
+        __syncthreads();
+        float fin[CT][NR];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+#pragma unroll
+            for (int k2 = 0; k2 < WK; ++k2) {
+                const float* src = red + ((k2 * CT + t) << 10) + ((wk * NR) << 6) + lane;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) fin[t][j] = k2 == 0 ? src[j << 6] : fin[t][j] + src[j << 6];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int nt = cg * CT + t;
+            if (nt >= a.NT) break;
+            if (ACT == 3) {
+                // rope image: see gptq_gemm_body.h (the same epilogue on the same image)
+                const int per = a.rD >> 5;
+                const int head = nt / per, tt = nt - head * per;
+                const bool roth = head < a.rH + a.rHkv;
+                const int d = roth ? ((c < 16) ? 16 * tt + c : (a.rD >> 1) + 16 * tt + (c - 16)) : 32 * tt + c;
+                const int col = head * a.rD + d;
+                const float bv = a.bias ? (float)a.bias[col] : 0.f;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int m = row_of(mr, j);
+                    const float mine = (float)(f16)(fin[t][j] + bv);
+                    float o = mine;
+                    if (roth) {
+                        const float other = __shfl_xor(mine, 16, 64);
+                        const float cf = (float)rcos[mr][t][j], sf = (float)rsin[mr][t][j];
+                        o = (c < 16) ? mine * cf - other * sf : other * sf + mine * cf;
+                    }
+                    const f16 oh = (f16)o;
+                    if (m < mrows) {
+                        if (head < a.rH) {
+                            a.out[(int64_t)m * a.ldo + col] = oh;
+                        } else {
+                            const int page = rslot[mr][j] >> 5, tok = rslot[mr][j] & 31;
+                            if (roth)
+                                a.kpool[((int64_t)page * a.rHkv + (head - a.rH)) * 32 * a.rD + k_off(tok, d, a.rD)] = oh;
+                            else
+                                a.vpool[((int64_t)page * a.rHkv + (head - a.rH - a.rHkv)) * 32 * a.rD + (int64_t)d * 32 +
+                                        v_col(tok)] = oh;
+                        }
+                    }
+                }
+                continue;
+            }
+            const int n = nt * 32 + c;
+            if (ACT == 2) {
+                // interleaved gate / up image: lanes c < 16 hold gate column j2, lanes c + 16 the matching up column
+                const int half = a.N >> 1;
+                const int j2 = nt * 16 + (c & 15);
+                const int nsrc = (c < 16) ? j2 : half + j2;
+                const float bv = (a.bias && j2 < half) ? (float)a.bias[nsrc] : 0.f;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const float mine = (float)(f16)(fin[t][j] + bv);
+                    const float other = __shfl_xor(mine, 16, 64);
+                    const int m = row_of(mr, j);
+                    if (c < 16 && j2 < half && m < mrows) {
+                        const float sl = mine / (1.f + __expf(-mine));
+                        const f16 o = (f16)((float)(f16)sl * other);
+                        if (OUTF)
+                            a.out[xf_off(m, j2, half)] = o;
+                        else
+                            a.out[(int64_t)m * a.ldo + j2] = o;
+                    }
+                }
+                continue;
+            }
+            if (a.S == 1 && !a.partial) {
+                const float bv = (a.bias && n < a.N) ? (float)a.bias[n] : 0.f;
+                if (n < a.N) {
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        const int m = row_of(mr, j);
+                        if (m < mrows) a.out[(int64_t)m * a.ldo + n] = (f16)(fin[t][j] + bv);
+                    }
+                }
+            } else {
+                // slabs in 32-row units: [row block][split][32][ld]
+                float* sl = a.slabs + ((int64_t)(mr * a.S + split) * 32) * (a.NT * 32) + n;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) sl[(int64_t)(row_of(mr, j) & 31) * (a.NT * 32)] = fin[t][j];
+            }
         }
     }
 }

@@ -103,7 +103,7 @@ struct NormPhase {
     void* res_out;        // T [rows, hidden]: x (+ residual), the residual stream (may alias nothing the launch reads)
     int rows, hidden;
     float eps;
-    int y_frag;           // 1: y leaves in 32-row fragment order (xf_off in common.h; rows <= 32, hidden % 64 == 0)
+    int y_frag;           // 1: y leaves in 32-row fragment order (xf_off in common.h; rows <= 64, hidden % 64 == 0)
 };
 
 // One row by all `nthreads` threads of the workgroup (nthreads a multiple of 64, <= 1024); `sh` = >= 16 floats of LDS that

@@ -161,8 +161,8 @@ static int launch_norm(const void* x, const void* residual, const void* weight, 
                    "norm: hidden (%ld) must be a multiple of 8 and <= %d", (long)hidden, MAX_HIDDEN);
     TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "norm: bad dtype");
     const int y_frag = ldy == TGIS_LD_FRAGMENTS;
-    TGIS_CHECK_ARG(ldy == 0 || ldy == hidden || (y_frag && RMS && rows <= 32 && hidden % 64 == 0),
-                   "norm: y is [rows, hidden] contiguous (ldy = 0 or hidden), or — RMSNorm, rows <= 32, hidden %% 64 == 0 — in "
+    TGIS_CHECK_ARG(ldy == 0 || ldy == hidden || (y_frag && RMS && rows <= 64 && hidden % 64 == 0),
+                   "norm: y is [rows, hidden] contiguous (ldy = 0 or hidden), or — RMSNorm, rows <= 64, hidden %% 64 == 0 — in "
                    "fragment order (ldy = TGIS_LD_FRAGMENTS)");
     if (rows == 0) return TGIS_OK;
     hipStream_t st = (hipStream_t)stream;

@@ -79,8 +79,8 @@ class KVArgs:
 
 
 def frag_rows(linear, rows: int, kv: "KVArgs", act: int = 0) -> bool:
-    """Decode step of <= 32 rows in front of an int4 linear that takes its operand in fragment order (native.FragAct)."""
-    return (kv.max_q_len == 1 and not kv.fresh_prefill and rows <= 32 and hasattr(linear, "wants_fragments")
+    """Decode step of <= 64 rows in front of an int4 linear that takes its operand in fragment order (native.FragAct)."""
+    return (kv.max_q_len == 1 and not kv.fresh_prefill and rows <= 64 and hasattr(linear, "wants_fragments")
             and linear.wants_fragments(rows, act))
 
 

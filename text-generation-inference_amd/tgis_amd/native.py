@@ -201,11 +201,11 @@ LD_FRAGMENTS = -32
 
 
 class FragAct:
-    """A [M <= 32, K] f16 activation stored in fragment order (include/tgis_hip.h, TGIS_LD_FRAGMENTS): what the decode
-    step's norm / attention / SiLU epilogue hand to the int4 GEMM behind them.  `buf` always holds 32 * K elements."""
+    """A [M <= 64, K] f16 activation stored in fragment order (include/tgis_hip.h, TGIS_LD_FRAGMENTS): what the decode
+    step's norm / attention / SiLU epilogue hand to the int4 GEMM behind them.  `buf` holds ceil(M / 32) * 32 * K elements."""
 
     def __init__(self, buf: torch.Tensor, M: int, K: int):
-        assert buf.dtype == torch.float16 and buf.numel() == 32 * K and K % 64 == 0 and 1 <= M <= 32
+        assert 1 <= M <= 64 and K % 64 == 0 and buf.dtype == torch.float16 and buf.numel() == (M + 31) // 32 * 32 * K
         self.buf, self.M, self.K = buf, M, K
         self.dtype, self.device = buf.dtype, buf.device
 
@@ -215,21 +215,22 @@ class FragAct:
 
     @staticmethod
     def empty(M: int, K: int, device) -> "FragAct":
-        return FragAct(torch.empty(32 * K, dtype=torch.float16, device=device), M, K)
+        return FragAct(torch.empty((M + 31) // 32 * 32 * K, dtype=torch.float16, device=device), M, K)
 
     @staticmethod
     def from_rows(x: torch.Tensor) -> "FragAct":
         """Row-major [M, K] -> fragment order (torch ops; tests and cold paths only)."""
         M, K = x.shape
-        full = torch.zeros((32, K), dtype=x.dtype, device=x.device)
+        rb = (M + 31) // 32
+        full = torch.zeros((rb * 32, K), dtype=x.dtype, device=x.device)
         full[:M] = x
-        # (m, step, half, i, e) -> [step][i][half][m][e]
-        f = full.view(32, K // 64, 2, 4, 8).permute(1, 3, 2, 0, 4).contiguous().view(-1)
+        # (row block, m, step, half, i, e) -> [row block][step][i][half][m][e]
+        f = full.view(rb, 32, K // 64, 2, 4, 8).permute(0, 2, 4, 3, 1, 5).contiguous().view(-1)
         return FragAct(f, M, K)
 
     def to_rows(self) -> torch.Tensor:
-        K = self.K
-        return self.buf.view(K // 64, 4, 2, 32, 8).permute(3, 0, 2, 1, 4).reshape(32, K)[:self.M].contiguous()
+        K, rb = self.K, (self.M + 31) // 32
+        return self.buf.view(rb, K // 64, 4, 2, 32, 8).permute(0, 4, 1, 3, 2, 5).reshape(rb * 32, K)[:self.M].contiguous()
 
 
 def gptq_fragments_ok(M: int, w: "GptqWeight", act: int = 0) -> bool:
@@ -527,7 +528,7 @@ def rmsnorm_residual(x, residual, weight, eps: float, y=None, res_out=None, frag
     rows, hidden = x.shape
     yf = None
     if frag:
-        assert y is None and rows <= 32 and hidden % 64 == 0 and x.dtype == torch.float16
+        assert y is None and rows <= 64 and hidden % 64 == 0 and x.dtype == torch.float16
         yf = FragAct.empty(rows, hidden, x.device)
         y, ldy = yf.buf, LD_FRAGMENTS
     else:

@@ -164,7 +164,7 @@ class Ex4bitLinearV2:
         if act == 2 and not self.gate_up:
             act = 0
         w = self.rope_handle if act == 3 else self.q_handle
-        return w is not None and rows <= 32 and native.gptq_fragments_ok(rows, w, act)
+        return w is not None and rows <= 64 and native.gptq_fragments_ok(rows, w, act)
 
     def forward(self, x, act: int = 0, partial: bool = False, out_frag: bool = False):
         """partial=True (decode-sized M only): return native.Partial — the consumer kernel finishes the split-K sum.
