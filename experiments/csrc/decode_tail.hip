@@ -396,9 +396,11 @@ __device__ __forceinline__ void run_rope(const RopePhase& p, const RopePre<T>& p
             st16(kb + k_off(tok, j * 8, p.D), a);
         } else if (is_v) {
             st16(hp + j * 8, a);
-            T* vb = vpool + ((int64_t)page * p.Hkv + (head - p.H - p.Hkv)) * 32 * p.D + v_col(tok);
+            // V block: [4 column groups][D][8] (csrc/kv_layout.h, round 4)
+            const int cp = v_col(tok);
+            T* vb = vpool + ((int64_t)page * p.Hkv + (head - p.H - p.Hkv)) * 32 * p.D + ((int64_t)((cp >> 3) * p.D + j * 8) << 3) + (cp & 7);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) vb[(int64_t)(j * 8 + e) * 32] = a[e];
+            for (int e = 0; e < 8; ++e) vb[e * 8] = a[e];
         } else {
             st16(hp + j * 8, a);  // q chunk outside the rotary span
         }

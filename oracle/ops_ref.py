@@ -193,7 +193,7 @@ def kv_page_unpack(k_pool: torch.Tensor, v_pool: torch.Tensor, page: int, Hkv: i
     """Return (K[32,Hkv,D], V[32,Hkv,D]) for one page of the pools [num_pages, Hkv, 32*D]."""
     kb = k_pool[page].reshape(Hkv, 2, D // 8, 16, 8)  # [h][tile][chunk][tok][8]
     K = kb.permute(1, 3, 0, 2, 4).reshape(32, Hkv, D)
-    vb = v_pool[page].reshape(Hkv, D, 32)  # [h][d][col]
+    vb = v_pool[page].reshape(Hkv, 4, D, 8).permute(0, 2, 1, 3).reshape(Hkv, D, 32)  # [h][column group][d][8] -> [h][d][col]
     tok = torch.arange(32)
     i = tok & 15
     col = (i >> 2) * 8 + (tok >> 4) * 4 + (i & 3)

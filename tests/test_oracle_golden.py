@@ -90,7 +90,8 @@ def test_kv_page_layout_roundtrip():
                 off = ((((tok >> 4) * (D >> 3) + (d >> 3)) * 16 + (tok & 15)) << 3) + (d & 7)
                 kp[0, h, off] = K[tok, h, d]
                 i = tok & 15
-                vp[0, h, d * 32 + (i >> 2) * 8 + (tok >> 4) * 4 + (i & 3)] = V[tok, h, d]
+                col = (i >> 2) * 8 + (tok >> 4) * 4 + (i & 3)
+                vp[0, h, ((col >> 3) * D + d) * 8 + (col & 7)] = V[tok, h, d]
     K2, V2 = ops_ref.kv_page_unpack(kp, vp, 0, Hkv, D)
     assert torch.equal(K2, K) and torch.equal(V2, V)
 

@@ -141,9 +141,9 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
             } else if (tid < 2 * C8) {
                 const int j = tid - C8;
                 const V8 v = roped8(a.H + a.Hkv + hk, j * 8, false);
-                T* vb = const_cast<T*>(reinterpret_cast<const T*>(a.vpool)) + ((int64_t)page * a.Hkv + hk) * 32 * D + v_col(tok);
+                T* vb = const_cast<T*>(reinterpret_cast<const T*>(a.vpool)) + ((int64_t)page * a.Hkv + hk) * 32 * D + v_off(tok, 0, D);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) vb[(int64_t)(j * 8 + e) * 32] = v[e];
+                for (int e = 0; e < 8; ++e) vb[(int64_t)(j * 8 + e) * 8] = v[e];
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left this CU before any wave reads the page
             __syncthreads();
@@ -164,14 +164,14 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     // one page of K (two 16-token halves x KS k-steps) and V^T (NB 16-row blocks): 16 KiB per wave at D = 128
     auto load_page = [&](const int pg, V8 (&kf)[2][KS], V8 (&vf)[NB]) {
         const T* kb = reinterpret_cast<const T*>(a.kpool) + ((int64_t)pg * a.Hkv + hk) * (32 * D) + lane * 8;
-        const T* vb = reinterpret_cast<const T*>(a.vpool) + ((int64_t)pg * a.Hkv + hk) * (32 * D) + col * 32 + c * 8;
+        const T* vb = reinterpret_cast<const T*>(a.vpool) + ((int64_t)pg * a.Hkv + hk) * (32 * D) + c * (D * 8) + col * 8;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) kf[t][ks] = __builtin_nontemporal_load(
                 reinterpret_cast<const V8*>(kb + t * (16 * D) + ks * 512));
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) vf[nb] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(vb + nb * 512));
+        for (int nb = 0; nb < NB; ++nb) vf[nb] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(vb + nb * 128));
     };
     // FULL: every key of the page is visible to every valid column (all but the last page of a decode step) — no
     // masks.  The softmax reference m[ch] is only moved when a tile maximum exceeds it by more than 2^RESCALE_LOG2

@@ -9,7 +9,7 @@
 //
 // LDS images of a page (16 KiB): K as in global memory ([tile][D/8][16 tokens][8]: a fragment is one contiguous KiB,
 // lane l reads piece l); V^T regrouped to [D/16][4 chunks][16 rows][8 token columns] so that lane (row l&15, chunk
-// l>>4) again reads piece l of a contiguous KiB (the global [D][32] order would put 8 lanes on 2 banks).
+// l>>4) again reads piece l of a contiguous KiB (the global [4 chunks][D][8] order would spread a fragment over four runs).
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs a) {
         for (int i = 0; i < NP / 2; ++i) {
             const int piece = i * 256 + tid;
             st16(kl + piece * 8, stage[i]);
-            // global V^T piece = (row d, chunk cc); LDS piece = (d/16)*64 + cc*16 + d%16
-            const int d = piece >> 2, cc = piece & 3;
+            // global V^T piece = (chunk cc, row d) ([4][D][8]); LDS piece = (d/16)*64 + cc*16 + d%16
+            const int d = piece % D, cc = piece / D;
             st16(vl + (((d >> 4) * 64 + cc * 16 + (d & 15)) * 8), stage[NP / 2 + i]);
         }
     };

@@ -366,8 +366,7 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
                             if (roth)
                                 kpool[((int64_t)page * a.rHkv + (head - a.rH)) * 32 * a.rD + k_off(tok, d, a.rD)] = oh;
                             else
-                                vpool[((int64_t)page * a.rHkv + (head - a.rH - a.rHkv)) * 32 * a.rD + (int64_t)d * 32 +
-                                      v_col(tok)] = oh;
+                                vpool[((int64_t)page * a.rHkv + (head - a.rH - a.rHkv)) * 32 * a.rD + v_off(tok, d, a.rD)] = oh;
                         }
                     }
                 }

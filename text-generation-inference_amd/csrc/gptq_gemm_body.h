@@ -615,8 +615,7 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
                         if (roth)
                             a.kpool[((int64_t)page * a.rHkv + (head - a.rH)) * 32 * a.rD + k_off(tok, d, a.rD)] = oh;
                         else
-                            a.vpool[((int64_t)page * a.rHkv + (head - a.rH - a.rHkv)) * 32 * a.rD + (int64_t)d * 32 +
-                                    v_col(tok)] = oh;
+                            a.vpool[((int64_t)page * a.rHkv + (head - a.rH - a.rHkv)) * 32 * a.rD + v_off(tok, d, a.rD)] = oh;
                     }
                 }
             }

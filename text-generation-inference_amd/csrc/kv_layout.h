@@ -2,7 +2,10 @@
 // the qkv activation (fp32 split-K slabs of the qkv GEMM that the consumer sums itself).  Shared by rope_kv.hip (the
 // stand-alone rotary + cache-write kernels) and attention.hip (the decode kernel that does both in its prologue).
 //   K: [tile=tok>>4][D/8][16 tokens][8]      -> MFMA 16x16x32 A-fragments are 1 KiB contiguous loads
-//   V: [D][32], token tok at column (i>>2)*8 + tile*4 + (i&3), i = tok&15 -> V^T A-fragments likewise
+//   V: [4 column groups][D][8], token tok in column v_col(tok) = (i>>2)*8 + tile*4 + (i&3), i = tok&15 (column group =
+//      v_col >> 3, slot = v_col & 7) -> a V^T A-fragment (16 rows d x 32 token columns) is four contiguous 256-byte runs of
+//      whole cache lines, and the d run of ONE token (a decode step's write) is 16-byte strided: 16 cache lines per head
+//      where the [D][32] order of rounds 1-3 touched 64 (round 4: the qkv + rotary launch 15.9 -> 12.6 us with cold pages)
 #pragma once
 #include "common.h"
 
@@ -12,6 +15,11 @@ __device__ __forceinline__ int64_t k_off(int tok, int d, int D) {
 __device__ __forceinline__ int v_col(int tok) {
     int i = tok & 15;
     return (i >> 2) * 8 + (tok >> 4) * 4 + (i & 3);
+}
+// element offset of (token tok, dim d) inside the V block of one (page, kv head)
+__device__ __forceinline__ int64_t v_off(int tok, int d, int D) {
+    const int cp = v_col(tok);
+    return ((int64_t)((cp >> 3) * D + d) << 3) + (cp & 7);
 }
 
 template <typename T> struct PartialIn {

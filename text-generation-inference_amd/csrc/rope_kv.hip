@@ -6,7 +6,7 @@
 //
 // KV page block layout for one (page, kv head), 32 tokens x D elements:
 //   K: [tile=tok>>4][D/8][16 tokens][8]      -> MFMA 16x16x32 A-fragments are 1 KiB contiguous loads
-//   V: [D][32], token tok at column (i>>2)*8 + tile*4 + (i&3), i = tok&15 -> V^T A-fragments likewise
+//   V: [4 column groups][D][8], token tok in column (i>>2)*8 + tile*4 + (i&3), i = tok&15 (kv_layout.h)
 #include <algorithm>
 #include "common.h"
 #include "kv_layout.h"
@@ -64,9 +64,9 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* qkv, int64_t ld, const 
         } else if (is_v) {
             if (pin.slabs) st16(hp + j * 8, a);
             if (!vpool) continue;
-            T* vb = vpool + ((int64_t)page * Hkv + (head - H - Hkv)) * 32 * D + v_col(tok);
+            T* vb = vpool + ((int64_t)page * Hkv + (head - H - Hkv)) * 32 * D + v_off(tok, j * 8, D);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) vb[(int64_t)(j * 8 + e) * 32] = a[e];
+            for (int e = 0; e < 8; ++e) vb[e * 8] = a[e];
         } else if (pin.slabs) {
             st16(hp + j * 8, a);  // un-rotated q chunk (no rope / beyond the rotary span)
         }
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* qkv, int64_t ld, const 
 
 // Prefill form of the cache write: one block per (sequence, 32-token page, kv head).  The page's k rows are rotated and
 // stored 16 tokens x 16 bytes at a time (contiguous 256-byte runs of the K layout); its v rows are transposed through
-// LDS so that every store is a full 16-byte run of the [D][32] layout.  The per-token kernel above issues 16-byte
+// LDS so that every store is a full 16-byte run of the [column group][D][8] layout (consecutive threads: consecutive runs).  The per-token kernel above issues 16-byte
 // (k) and 2-byte (v) stores scattered over the page: fine for the 32 tokens of a decode step, ~4x slower than this on a
 // 32k-token prefill.  Precondition: token i of sequence b sits at cache position i (a fresh prefill; its rotary
 // position comes from `positions` like everywhere else).  Slots of the last page past the sequence end get zeros.
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void rope_kv_prefill_kernel(const T* __restric
         if (pair) st16(kb + k_off(tok, (j + rh8) * 8, D), o2);
     }
 
-    // ---- V: stage [token][d] rows, store [d][8 token columns] runs ----------------------------------------------
+    // ---- V: stage [token][d] rows, store [column group][d][8 token columns] runs ----------------------------------------------
     const int rs = D + 8;
     for (int it = tid; it < 32 * c8; it += 256) {
         const int tok = it / c8, j = it - tok * c8;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void rope_kv_prefill_kernel(const T* __restric
             o[e] = vs[(c * 4 + e) * rs + d];
             o[e + 4] = vs[(16 + c * 4 + e) * rs + d];
         }
-        st16(vb + (int64_t)d * 32 + c * 8, o);
+        st16(vb + ((int64_t)c * D + d) * 8, o);
     }
 }
 

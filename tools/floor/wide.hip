@@ -52,11 +52,18 @@ struct Args {
     int M, K, N, NT, KS, G, spg_shift;
     int S, steps;          // global splits, real k64-steps (K / 64)
     long long* trace;      // [blocks][WK][8] s_memtime stamps (nullptr: off)
+    // EPI 3.. (rope epilogue as in gptq_wide_body.h ACT 3)
+    const int32_t* positions; const int32_t* slots; const f16* cosb; const f16* sinb; f16* kpool; f16* vpool;
+    int rH, rHkv, rD;
 };
+__device__ __forceinline__ int64_t k_off(int tok, int d, int D) {
+    return ((int64_t)(((tok >> 4) * (D >> 3) + (d >> 3)) * 16 + (tok & 15)) << 3) + (d & 7);
+}
+__device__ __forceinline__ int v_col(int tok) { int i = tok & 15; return (i >> 2) * 8 + (tok >> 4) * 4 + (i & 3); }
 #define STAMP(i) do { if (TR) { stamp[i] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
 
 // MODE: 0 full; 1 no arithmetic (loads, waits, reduce, stores); 2 no x loads (A = weights); 3 no weight loads beyond prologue
-template <int CT, int WK, int DEPTH, int MODE, int XF = 0, int ORD = 0, bool TR = false>
+template <int CT, int WK, int DEPTH, int MODE, int XF = 0, int ORD = 0, bool TR = false, int EPI = 0>
 __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -120,6 +127,37 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
         }
     };
 
+    constexpr int NR_ = 16 / WK;
+    int32_t rpos[NR_], rslot[NR_];
+    if (EPI >= 3) {
+#pragma unroll
+        for (int j = 0; j < NR_; ++j) {
+            const int r = wk * NR_ + j;
+            const int m = min((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), mrows - 1);
+            rpos[j] = a.positions[m];
+            rslot[j] = a.slots[m];
+        }
+    }
+    uint32_t touch = 0;
+    if (EPI == 7) {   // touch the cache lines the epilogue will write (k / v heads), so that its partial-line stores hit
+        const int per = a.rD >> 5, c = lane & 31;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int nt = min(cg * CT + t, a.NT - 1);
+            const int head = nt / per, tt = nt - head * per;
+            const bool roth = head < a.rH + a.rHkv;
+            const int d = roth ? ((c < 16) ? 16 * tt + c : (a.rD >> 1) + 16 * tt + (c - 16)) : 32 * tt + c;
+            if (head >= a.rH) {
+#pragma unroll
+                for (int j = 0; j < NR_; ++j) {
+                    const int page = rslot[j] >> 5, tok = rslot[j] & 31;
+                    const f16* p = roth ? a.kpool + ((int64_t)page * a.rHkv + (head - a.rH)) * 32 * a.rD + k_off(tok, d, a.rD)
+                                        : a.vpool + ((int64_t)page * a.rHkv + (head - a.rH - a.rHkv)) * 32 * a.rD + (int64_t)d * 32 + v_col(tok);
+                    touch += *(const volatile uint16_t*)p;
+                }
+            }
+        }
+    }
     uint32_t EXr = 0x64006400u, M0r = 0x000F000Fu, M1r = 0x00F000F0u;
     asm volatile("" : "+v"(EXr));
     asm volatile("" : "+s"(M0r), "+s"(M1r));
@@ -197,8 +235,24 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
         if (s + d < s1) consume(d);
     STAMP(4);
 
-    // ---- k-part sum through LDS, distributed finish: wave wk ends up with registers [wk NR, (wk+1) NR) of every tile ----
     constexpr int NR = 16 / WK;
+    f16 rcos[CT][NR], rsin[CT][NR];
+    if (EPI >= 3 && EPI != 5) {
+        const int per = a.rD >> 5;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int nt = min(cg * CT + t, a.NT - 1);
+            const int tt = nt - (nt / per) * per;
+            const int dr = 16 * tt + (lane & 15);
+            const bool roth = nt / per < a.rH + a.rHkv;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                rcos[t][j] = roth ? a.cosb[(int64_t)rpos[j] * (a.rD >> 1) + dr] : (f16)1.f;
+                rsin[t][j] = roth ? a.sinb[(int64_t)rpos[j] * (a.rD >> 1) + dr] : (f16)0.f;
+            }
+        }
+    }
+    // ---- k-part sum through LDS, distributed finish: wave wk ends up with registers [wk NR, (wk+1) NR) of every tile ----
     float* red = reinterpret_cast<float*>(smem);  // [WK][CT][16 registers][64 lanes]: every access is 64 consecutive words
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
@@ -224,6 +278,42 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
         const int nt = cg * CT + t;
         if (nt >= a.NT) break;
         const int n = nt * 32 + c;
+        if (EPI >= 3) {
+            const int per = a.rD >> 5;
+            const int head = nt / per, tt = nt - head * per;
+            const bool roth = head < a.rH + a.rHkv;
+            const int d = roth ? ((c < 16) ? 16 * tt + c : (a.rD >> 1) + 16 * tt + (c - 16)) : 32 * tt + c;
+            const int col = head * a.rD + d;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int r = wk * NR + j;
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float mine = (float)(f16)(fin[t][j]);
+                float o = mine;
+                if (roth && EPI != 5) {
+                    const float other = __shfl_xor(mine, 16, 64);
+                    const float cf = (float)rcos[t][j], sf = (float)rsin[t][j];
+                    o = (c < 16) ? mine * cf - other * sf : other * sf + mine * cf;
+                }
+                const f16 oh = (f16)o;
+                if (m < mrows) {
+                    if (head < a.rH || EPI == 6) {
+                        a.out[(int64_t)m * a.ldo + col] = oh;
+                    } else {
+                        const int page = rslot[j] >> 5, tok = rslot[j] & 31;
+                        if (roth)
+                            a.kpool[((int64_t)page * a.rHkv + (head - a.rH)) * 32 * a.rD + k_off(tok, d, a.rD)] = oh;
+                        else if (EPI == 8)   // V page as [tok / 8][D][8]: a token's d run is 16-byte strided (16 lines per head instead of 64)
+                            a.vpool[((int64_t)page * a.rHkv + (head - a.rH - a.rHkv)) * 32 * a.rD + (int64_t)(tok >> 3) * 8 * a.rD + d * 8 + (tok & 7)] = oh;
+                        else if (EPI == 4)   // v written row-major into the q tensor's space: what does the scatter cost?
+                            a.out[(int64_t)m * a.ldo + col] = oh;
+                        else
+                            a.vpool[((int64_t)page * a.rHkv + (head - a.rH - a.rHkv)) * 32 * a.rD + (int64_t)d * 32 + v_col(tok)] = oh;
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const int r = wk * NR + j;
@@ -236,6 +326,7 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
         }
     }
     STAMP(6);
+    if (EPI == 7 && touch == 0x12345u) a.out[0] = (f16)1.f;
     if (TR && lane == 0) {
         long long* tp = a.trace + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WK + wk) * 8;
 #pragma unroll
@@ -299,20 +390,24 @@ static double ref_dot(const Image& im, const std::vector<f16>& x, int ldx, int m
 
 static const f16* g_xf = nullptr;
 static int g_ldx = 0;
-template <int CT, int WK, int DEPTH, int MODE, int XF = 0, int ORD = 0>
+static std::vector<int32_t*> g_slotsets;
+static Args g_rope;  // rope epilogue operands (positions, slots, tables, pools)
+template <int CT, int WK, int DEPTH, int MODE, int XF = 0, int ORD = 0, int EPI = 0>
 static float run(const Image& im, const std::vector<uint8_t*>& sets, const f16* dx, f16* dout, float* dslabs, int M, int S,
                  int iters, bool check, const std::vector<f16>& hx) {
     Args a;
     a.x = dx; a.ldx = g_ldx; a.xf = g_xf; a.out = dout; a.ldo = im.N; a.slabs = dslabs;
     a.M = M; a.K = im.K; a.N = im.N; a.NT = im.NT; a.KS = im.KS; a.G = im.G;
     a.offB = im.offB; a.S = S; a.steps = im.K / 64; a.trace = nullptr;
+    a.positions = g_rope.positions; a.slots = g_rope.slots; a.cosb = g_rope.cosb; a.sinb = g_rope.sinb;
+    a.kpool = g_rope.kpool; a.vpool = g_rope.vpool; a.rH = 32; a.rHkv = 32; a.rD = 128;
     int spg = im.gs / 64, sh = 0;
     while ((1 << sh) < spg) ++sh;
     a.spg_shift = sh;
     const int cgs = (im.NT + CT - 1) / CT;
     const size_t lds = (size_t)WK * CT * 4096;
-    CK(hipFuncSetAttribute((const void*)wide_gemm<CT, WK, DEPTH, MODE, XF, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CK(hipFuncSetAttribute((const void*)wide_gemm<CT, WK, DEPTH, MODE, XF, ORD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)wide_gemm<CT, WK, DEPTH, MODE, XF, ORD, false, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)wide_gemm<CT, WK, DEPTH, MODE, XF, ORD, true, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(cgs, S);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e9;
@@ -320,7 +415,8 @@ static float run(const Image& im, const std::vector<uint8_t*>& sets, const f16* 
         CK(hipEventRecord(e0, 0));
         for (int i = 0; i < iters; ++i) {
             a.prep = sets[i % sets.size()];
-            hipLaunchKernelGGL((wide_gemm<CT, WK, DEPTH, MODE, XF, ORD>), grid, dim3(64 * WK), lds, 0, a);
+            if (EPI >= 3 && getenv("WIDE_COLD")) a.slots = g_slotsets[i % g_slotsets.size()];
+            hipLaunchKernelGGL((wide_gemm<CT, WK, DEPTH, MODE, XF, ORD, false, EPI>), grid, dim3(64 * WK), lds, 0, a);
         }
         CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -332,7 +428,7 @@ static float run(const Image& im, const std::vector<uint8_t*>& sets, const f16* 
         a.trace = dtr;
         for (int i = 0; i < 4; ++i) {   // the last of a few cold launches
             a.prep = sets[(i + 3) % sets.size()];
-            hipLaunchKernelGGL((wide_gemm<CT, WK, DEPTH, MODE, XF, ORD, true>), grid, dim3(64 * WK), lds, 0, a);
+            hipLaunchKernelGGL((wide_gemm<CT, WK, DEPTH, MODE, XF, ORD, true, EPI>), grid, dim3(64 * WK), lds, 0, a);
         }
         CK(hipDeviceSynchronize());
         std::vector<long long> tr((size_t)nw * 8);
@@ -357,10 +453,10 @@ static float run(const Image& im, const std::vector<uint8_t*>& sets, const f16* 
         CK(hipFree(dtr));
     }
     double maxerr = 0;
-    if (check && MODE == 0) {
+    if (check && MODE == 0 && EPI == 0) {
         a.prep = sets[0];
         CK(hipMemset(dout, 0, (size_t)32 * im.N * 2));
-        hipLaunchKernelGGL((wide_gemm<CT, WK, DEPTH, MODE, XF, ORD>), grid, dim3(64 * WK), lds, 0, a);
+        hipLaunchKernelGGL((wide_gemm<CT, WK, DEPTH, MODE, XF, ORD, false, EPI>), grid, dim3(64 * WK), lds, 0, a);
         CK(hipDeviceSynchronize());
         std::vector<f16> ho((size_t)32 * im.N);
         std::vector<float> hs;
@@ -377,18 +473,35 @@ static float run(const Image& im, const std::vector<uint8_t*>& sets, const f16* 
     }
     const int blocks = cgs * S;
     const double mb = (double)(im.offB * 1.0 * (im.K / 64) / im.KS + (double)im.NT * im.G * 128) / 1e6;
-    printf("  CT %d WK %2d DEPTH %d S %2d mode %d xf %d ord %d ldx %d: blocks %4d  %6.2f us  %5.2f TB/s  relerr %.1e%s\n", CT, WK, DEPTH, S, MODE, XF, ORD, g_ldx, blocks, best,
+    printf("  CT %d WK %2d DEPTH %d S %2d mode %d xf %d ord %d epi %d ldx %d: blocks %4d  %6.2f us  %5.2f TB/s  relerr %.1e%s\n", CT, WK, DEPTH, S, MODE, XF, ORD, EPI, g_ldx, blocks, best,
            mb / best, maxerr, (check && MODE == 0 && maxerr > 3e-3) ? "  <-- WRONG" : "");
     return best;
 }
 
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 32;
+    {   // rope operands at the cfg3 shape: 32 rows, 32 + 32 + 32 heads of 128, one page of 32 tokens per (page, head)
+        std::vector<int32_t> pos(32), slots(32);
+        const int pages = 64 * 32;
+        for (int i = 0; i < 32; ++i) { pos[i] = 1000 + (rnd() % 48); slots[i] = (int)((rnd() % pages) * 32 + rnd() % 32); }
+        int32_t *dp, *ds; CK(hipMalloc(&dp, 128)); CK(hipMalloc(&ds, 128));
+        CK(hipMemcpy(dp, pos.data(), 128, hipMemcpyHostToDevice)); CK(hipMemcpy(ds, slots.data(), 128, hipMemcpyHostToDevice));
+        f16 *dc, *dsn, *kp, *vp;
+        CK(hipMalloc(&dc, 2048 * 64 * 2)); CK(hipMalloc(&dsn, 2048 * 64 * 2)); CK(hipMemset(dc, 0, 2048 * 64 * 2)); CK(hipMemset(dsn, 0, 2048 * 64 * 2));
+        CK(hipMalloc(&kp, (size_t)pages * 32 * 32 * 128 * 2)); CK(hipMalloc(&vp, (size_t)pages * 32 * 32 * 128 * 2));
+        for (int k = 0; k < 64; ++k) {
+            std::vector<int32_t> sl(32);
+            for (int i = 0; i < 32; ++i) sl[i] = (int)((rnd() % pages) * 32 + rnd() % 32);
+            int32_t* d; CK(hipMalloc(&d, 128)); CK(hipMemcpy(d, sl.data(), 128, hipMemcpyHostToDevice));
+            g_slotsets.push_back(d);
+        }
+        g_rope.positions = dp; g_rope.slots = ds; g_rope.cosb = dc; g_rope.sinb = dsn; g_rope.kpool = kp; g_rope.vpool = vp;
+    }
     struct Shape { const char* name; int K, N; } shapes[] = {
         {"qkv 4096x12288", 4096, 12288}, {"o 4096x4096", 4096, 4096}, {"gate_up 4096x22016", 4096, 22016}, {"down 11008x4096", 11008, 4096}};
     for (auto& sh : shapes) {
         Image im = make_image(sh.K, sh.N, 128);
-        const int nsets = (int)std::max<int64_t>(2, (700ll << 20) / im.total);
+        const int nsets = getenv("WIDE_ONESET") ? 1 : (int)std::max<int64_t>(2, (700ll << 20) / im.total);
         std::vector<uint8_t*> sets(nsets);
         for (int i = 0; i < nsets; ++i) {
             CK(hipMalloc(&sets[i], im.total));
@@ -410,15 +523,15 @@ int main(int argc, char** argv) {
         f16* dout; CK(hipMalloc(&dout, (size_t)32 * sh.N * 2));
         float* dslabs; CK(hipMalloc(&dslabs, (size_t)16 * 32 * im.NT * 32 * 4));
         printf("%s  (%.1f MB image, %d rotating sets, M = %d)\n", sh.name, im.total / 1e6, nsets, M);
-        const int it = 2 * nsets;
+        const int it = getenv("WIDE_ONESET") ? 40 : 2 * nsets;
 #define R(CT, WK, D, S) (g_ldx = sh.K, run<CT, WK, D, 0, 0, 1>(im, sets, dx, dout, dslabs, M, S, it, true, hx))
 #define RP(CT, WK, D, S) (g_ldx = sh.K + 64, run<CT, WK, D, 0, 0, 1>(im, sets, dxp, dout, dslabs, M, S, it, true, hx))
 #define RX(CT, WK, D, S) (g_ldx = sh.K, run<CT, WK, D, 0, 1, 1>(im, sets, dx, dout, dslabs, M, S, it, true, hx))
 #define RX0(CT, WK, D, S) (g_ldx = sh.K, run<CT, WK, D, 0, 1, 0>(im, sets, dx, dout, dslabs, M, S, it, true, hx))
+#define RE(CT, WK, D, S, EPI) (g_ldx = sh.K, run<CT, WK, D, 0, 1, 1, EPI>(im, sets, dx, dout, dslabs, M, S, it, false, hx))
 #define RM(CT, WK, D, S, MODE) (g_ldx = sh.K, run<CT, WK, D, MODE, 1, 1>(im, sets, dx, dout, dslabs, M, S, it, false, hx))
         if (sh.N == 12288) {
-            RX(3, 8, 2, 2); RM(3, 8, 2, 2, 6); RM(3, 8, 2, 2, 7); RM(3, 8, 2, 2, 4);
-            RX(2, 16, 2, 1); RX(2, 8, 2, 1); RX(1, 8, 2, 1); RX(1, 16, 2, 1); RX(1, 8, 4, 1); RX(2, 8, 4, 1);
+            RX(2, 8, 2, 1); RE(2, 8, 2, 1, 3); RE(2, 8, 2, 1, 4); RE(2, 8, 2, 1, 5); RE(2, 8, 2, 1, 6); RE(2, 8, 2, 1, 7); RE(2, 8, 2, 1, 8);
         } else if (sh.N == 22016) {
             RX(3, 8, 2, 1); RM(3, 8, 2, 1, 6); RM(3, 8, 2, 1, 7); RM(3, 8, 2, 1, 4);
         } else if (sh.K == 11008) {
