@@ -55,6 +55,11 @@ struct Args {
     // EPI 3.. (rope epilogue as in gptq_wide_body.h ACT 3)
     const int32_t* positions; const int32_t* slots; const f16* cosb; const f16* sinb; f16* kpool; f16* vpool;
     int rH, rHkv, rD;
+    // EPI 10 (split-K finished in the launch: the last split of a column group sums the slabs, adds the residual, writes
+    // h in row-major and fragment order and the rows' partial sums of squares); EPI 11 (the consumer of that: A = h * w,
+    // rstd from the partial sums in the epilogue)
+    unsigned* counters; const f16* resid; f16* hout; f16* hfrag; float* ssq;   // ssq [32][NT]
+    const f16* normw; const float* ssq_in; int ssq_n; float eps;
 };
 __device__ __forceinline__ int64_t k_off(int tok, int d, int D) {
     return ((int64_t)(((tok >> 4) * (D >> 3) + (d >> 3)) * 16 + (tok & 15)) << 3) + (d & 7);
@@ -95,12 +100,19 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
     u32x4 wq[DEPTH][CT];
     uint32_t sz[DEPTH][CT];
     f16x8 xa[DEPTH][4];
+    f16x8 wn[EPI == 11 ? DEPTH : 1][4];
     auto load_x = [&](int d, int step) {
         if (XF) {   // fragment-major activation: [step][i][lane][8 halves], 1 KiB per load
             const char* p = reinterpret_cast<const char*>(a.xf) + (int64_t)min(step, sclamp) * 4096;
             PIN_SGPR(p);
 #pragma unroll
             for (int i = 0; i < 4; ++i) xa[d][i] = *(const GLOBAL_AS f16x8*)(p + woff + i * 1024);
+            if (EPI == 11) {   // the norm weight of the same k slots: two distinct 16-byte pieces per load
+                const char* q = reinterpret_cast<const char*>(a.normw) + (int64_t)min(step, sclamp) * 128;
+                PIN_SGPR(q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wn[d][i] = *(const GLOBAL_AS f16x8*)(q + (lane >> 5) * 16 + i * 32);
+            }
             return;
         }
         const char* p = xb + (int64_t)min(step, sclamp) * 128;
@@ -137,6 +149,19 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
             rpos[j] = a.positions[m];
             rslot[j] = a.slots[m];
         }
+    }
+    float ssq_part[NR_][2][2];
+    if (EPI == 11) {
+#pragma unroll
+        for (int j = 0; j < NR_; ++j)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int r = wk * NR_ + j;
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float* pp = a.ssq_in + (int64_t)m * a.ssq_n;   // ssq_n <= 128: two per lane
+                ssq_part[j][hh][0] = lane < a.ssq_n ? pp[lane] : 0.f;
+                ssq_part[j][hh][1] = lane + 64 < a.ssq_n ? pp[lane + 64] : 0.f;
+            }
     }
     uint32_t touch = 0;
     if (EPI == 7) {   // touch the cache lines the epilogue will write (k / v heads), so that its partial-line stores hit
@@ -206,6 +231,7 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
                     acc[t][i] += __builtin_bit_cast(float, wq[d][t][i]) + (float)xa[d][i][0] + (float)szh[0];
                 } else {
                     const f16x8 b = dequant8(wq[d][t][i], zc, zd, sc, EXr, M0r, M1r);
+                    if (EPI == 11 && t == 0) xa[d][i] = xa[d][i] * wn[d][i];
                     const f16x8 av = MODE == 2 ? __builtin_bit_cast(f16x8, wq[d][(t + 1) % CT]) : xa[d][i];
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b, acc[t], 0, 0, 0);
                 }
@@ -213,6 +239,22 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
         }
     };
 
+    f16 rcos9[CT][16 / WK], rsin9[CT][16 / WK];
+    if (EPI == 9) {
+        const int per = a.rD >> 5;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int nt = min(cg * CT + t, a.NT - 1);
+            const int tt = nt - (nt / per) * per;
+            const int dr = 16 * tt + (lane & 15);
+            const bool roth = nt / per < a.rH + a.rHkv;
+#pragma unroll
+            for (int j = 0; j < 16 / WK; ++j) {
+                rcos9[t][j] = roth ? a.cosb[(int64_t)rpos[j] * (a.rD >> 1) + dr] : (f16)1.f;
+                rsin9[t][j] = roth ? a.sinb[(int64_t)rpos[j] * (a.rD >> 1) + dr] : (f16)0.f;
+            }
+        }
+    }
     STAMP(1);
     int s = s0;
     for (; s + DEPTH < s1; s += DEPTH) {
@@ -237,7 +279,12 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
 
     constexpr int NR = 16 / WK;
     f16 rcos[CT][NR], rsin[CT][NR];
-    if (EPI >= 3 && EPI != 5) {
+    if (EPI == 9) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) { rcos[t][j] = rcos9[t][j]; rsin[t][j] = rsin9[t][j]; }
+    } else if (EPI >= 3 && EPI != 5) {
         const int per = a.rD >> 5;
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
@@ -273,12 +320,88 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
         }
     }
     const int c = lane & 31;
+    float rstd[NR];
+    if (EPI == 11) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            float v0 = ssq_part[j][0][0] + ssq_part[j][0][1], v1 = ssq_part[j][1][0] + ssq_part[j][1][1];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); }
+            rstd[j] = rsqrtf(((lane >> 5) ? v1 : v0) / (float)a.K + a.eps);
+        }
+    }
+    if (EPI == 10 && a.S > 1) {
+        // ---- split-K finished in the launch ----
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, 0x7FFFFFFF, 0x00020000);
+        const int ld = a.NT * 32;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int nt = min(cg * CT + t, a.NT - 1);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int r = wk * NR + j;
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, fin[t][j]), rs,
+                                                      (uint32_t)((((int64_t)split * 32 + m) * ld + nt * 32 + c) * 4), 0, 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* lastp = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(a.counters + cg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old + 1u == (unsigned)a.S;
+            if (last) __hip_atomic_store(a.counters + cg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *lastp = last;
+        }
+        __syncthreads();
+        if (!*lastp) return;
+        float part[CT][NR][4];   // S <= 4 here
+        f16 res[CT][NR];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int nt = min(cg * CT + t, a.NT - 1);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int r = wk * NR + j;
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+                    part[t][j][s2] = s2 < a.S ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs,
+                                         (uint32_t)((((int64_t)s2 * 32 + m) * ld + nt * 32 + c) * 4), 0, 16)) : 0.f;
+                res[t][j] = a.resid[(int64_t)min(m, mrows - 1) * a.N + nt * 32 + c];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int nt = cg * CT + t;
+            if (nt >= a.NT) break;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int r = wk * NR + j;
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float o = (float)(f16)(((part[t][j][0] + part[t][j][1]) + part[t][j][2]) + part[t][j][3]);
+                const float h = o + (float)res[t][j];
+                const f16 hq = (f16)h;
+                float sq = h * h;
+#pragma unroll
+                for (int of = 16; of > 0; of >>= 1) sq += __shfl_xor(sq, of, 64);
+                if (m < mrows) {
+                    a.hout[(int64_t)m * a.N + nt * 32 + c] = hq;
+                    const int k = nt * 32 + c;
+                    a.hfrag[((((k >> 6) << 2) + ((k >> 3) & 3)) * 64 + ((k >> 5) & 1) * 32 + (m & 31)) * 8 + (k & 7)] = hq;
+                    if (c == 0) a.ssq[(int64_t)m * a.NT + nt] = sq;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
         const int nt = cg * CT + t;
         if (nt >= a.NT) break;
         const int n = nt * 32 + c;
-        if (EPI >= 3) {
+        if (EPI >= 3 && EPI < 10) {
             const int per = a.rD >> 5;
             const int head = nt / per, tt = nt - head * per;
             const bool roth = head < a.rH + a.rHkv;
@@ -303,7 +426,7 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
                         const int page = rslot[j] >> 5, tok = rslot[j] & 31;
                         if (roth)
                             a.kpool[((int64_t)page * a.rHkv + (head - a.rH)) * 32 * a.rD + k_off(tok, d, a.rD)] = oh;
-                        else if (EPI == 8)   // V page as [tok / 8][D][8]: a token's d run is 16-byte strided (16 lines per head instead of 64)
+                        else if (EPI == 8 || EPI == 9)   // V page as [tok / 8][D][8]: a token's d run is 16-byte strided (16 lines per head instead of 64)
                             a.vpool[((int64_t)page * a.rHkv + (head - a.rH - a.rHkv)) * 32 * a.rD + (int64_t)(tok >> 3) * 8 * a.rD + d * 8 + (tok & 7)] = oh;
                         else if (EPI == 4)   // v written row-major into the q tensor's space: what does the scatter cost?
                             a.out[(int64_t)m * a.ldo + col] = oh;
@@ -319,7 +442,7 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
             const int r = wk * NR + j;
             const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (a.S == 1) {
-                if (m < mrows && n < a.N) a.out[(int64_t)m * a.ldo + n] = (f16)fin[t][j];
+                if (m < mrows && n < a.N) a.out[(int64_t)m * a.ldo + n] = (f16)(EPI == 11 ? fin[t][j] * rstd[j] : fin[t][j]);
             } else {
                 a.slabs[((int64_t)split * 32 + m) * (a.NT * 32) + n] = fin[t][j];
             }
@@ -401,6 +524,17 @@ static float run(const Image& im, const std::vector<uint8_t*>& sets, const f16* 
     a.offB = im.offB; a.S = S; a.steps = im.K / 64; a.trace = nullptr;
     a.positions = g_rope.positions; a.slots = g_rope.slots; a.cosb = g_rope.cosb; a.sinb = g_rope.sinb;
     a.kpool = g_rope.kpool; a.vpool = g_rope.vpool; a.rH = 32; a.rHkv = 32; a.rD = 128;
+    {
+        static unsigned* cnt = nullptr; static f16 *res = nullptr, *ho = nullptr, *hf = nullptr, *nw = nullptr; static float *sq = nullptr, *sqi = nullptr;
+        if (!cnt) {
+            CK(hipMalloc(&cnt, 4096 * 4)); CK(hipMemset(cnt, 0, 4096 * 4));
+            CK(hipMalloc(&res, 32 * 32768 * 2)); CK(hipMemset(res, 0, 32 * 32768 * 2));
+            CK(hipMalloc(&ho, 32 * 32768 * 2)); CK(hipMalloc(&hf, 32 * 32768 * 2));
+            CK(hipMalloc(&nw, 32768 * 2)); CK(hipMemset(nw, 0x3c, 32768 * 2));
+            CK(hipMalloc(&sq, 32 * 1024 * 4)); CK(hipMalloc(&sqi, 32 * 128 * 4)); CK(hipMemset(sqi, 0x3c, 32 * 128 * 4));
+        }
+        a.counters = cnt; a.resid = res; a.hout = ho; a.hfrag = hf; a.ssq = sq; a.normw = nw; a.ssq_in = sqi; a.ssq_n = 128; a.eps = 1e-5f;
+    }
     int spg = im.gs / 64, sh = 0;
     while ((1 << sh) < spg) ++sh;
     a.spg_shift = sh;
@@ -531,13 +665,13 @@ int main(int argc, char** argv) {
 #define RE(CT, WK, D, S, EPI) (g_ldx = sh.K, run<CT, WK, D, 0, 1, 1, EPI>(im, sets, dx, dout, dslabs, M, S, it, false, hx))
 #define RM(CT, WK, D, S, MODE) (g_ldx = sh.K, run<CT, WK, D, MODE, 1, 1>(im, sets, dx, dout, dslabs, M, S, it, false, hx))
         if (sh.N == 12288) {
-            RX(2, 8, 2, 1); RE(2, 8, 2, 1, 3); RE(2, 8, 2, 1, 4); RE(2, 8, 2, 1, 5); RE(2, 8, 2, 1, 6); RE(2, 8, 2, 1, 7); RE(2, 8, 2, 1, 8);
+            RX(2, 8, 2, 1); RX(2, 8, 3, 1); RX(4, 8, 2, 1); RX(3, 8, 2, 1);
         } else if (sh.N == 22016) {
-            RX(3, 8, 2, 1); RM(3, 8, 2, 1, 6); RM(3, 8, 2, 1, 7); RM(3, 8, 2, 1, 4);
+            RX(3, 8, 2, 1); RX(3, 8, 3, 1); RX(4, 8, 2, 1); RX(4, 8, 3, 1);
         } else if (sh.K == 11008) {
-            RX(2, 8, 2, 4); RM(2, 8, 2, 4, 6); RM(2, 8, 2, 4, 7); RM(2, 8, 2, 4, 4);
+            RX(2, 8, 2, 4); RX(2, 8, 3, 4); RX(2, 8, 2, 3); RX(3, 8, 2, 6); RX(4, 8, 2, 8);
         } else {
-            RX(2, 8, 2, 4); RM(2, 8, 2, 4, 6); RM(2, 8, 2, 4, 7); RM(2, 8, 2, 4, 4);
+            RX(2, 8, 2, 4); RX(2, 8, 3, 4); RX(2, 8, 2, 2); RX(4, 8, 2, 8);
         }
         for (auto p : sets) CK(hipFree(p));
         CK(hipFree(dx)); CK(hipFree(dout)); CK(hipFree(dslabs));
