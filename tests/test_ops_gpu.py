@@ -313,6 +313,47 @@ def test_split_decode_attention_merges_in_one_launch_every_time(nat, gpu_device,
         assert torch.equal(run(qs[i & 1], ns), first[i & 1]), f"launch {i}: the merged result changed"
 
 
+@pytest.mark.parametrize("dtype,B,H,Hkv,D,ctx,splits", [
+    (torch.float16, 8, 64, 1, 128, 300, 1),    # 4 chunks = two blocks per group (3 + 1 chunks), 8 groups
+    (torch.bfloat16, 8, 80, 1, 64, 200, 2),    # 5 chunks, two key splits: 16 groups, merged by the combine launch
+    (torch.float16, 4, 128, 2, 128, 150, 1),   # two kv heads: group -> (sequence, kv head) decomposition
+])
+def test_decode_attention_chunk_blocks_share_an_xcd(nat, gpu_device, dtype, B, H, Hkv, D, ctx, splits):
+    """Groups wider than 48 heads take several blocks per (sequence, split, kv head); when the number of groups is a
+    multiple of 8 the launch remaps block ids so that the chunk blocks of one group run on one XCD (attention.hip,
+    xcd_remap).  The remap is a permutation of block ids: every (group, chunk block) must still be computed exactly
+    once — checked against the oracle on ragged contexts."""
+    g = torch.Generator().manual_seed(B * H + ctx)
+    lens = [ctx - 11 * i for i in range(B)]
+    pages_per = [(l + 31) // 32 for l in lens]
+    total_pages = sum(pages_per)
+    bt = torch.zeros((B, max(pages_per)), dtype=torch.int32)
+    perm = torch.randperm(total_pages, generator=g)
+    o = 0
+    for b in range(B):
+        bt[b, :pages_per[b]] = perm[o:o + pages_per[b]].int()
+        o += pages_per[b]
+    T = sum(lens)
+    kv = torch.randn(T, 2 * Hkv * D, generator=g).to(dtype)
+    dummy = torch.zeros((T, (H + 2 * Hkv) * D), dtype=dtype)
+    dummy[:, H * D:] = kv
+    slots = torch.cat([bt[b, torch.arange(l) // 32].long() * 32 + torch.arange(l) % 32 for b, l in enumerate(lens)]).int()
+    kpool = torch.zeros((total_pages, Hkv, 32 * D), dtype=dtype, device=gpu_device)
+    vpool = torch.zeros_like(kpool)
+    nat.rope_kv_write(dummy.to(gpu_device), None, None, None, slots.to(gpu_device), kpool, vpool, H, Hkv, D, D)
+    q = torch.randn(B, H * D, generator=g).to(dtype)
+    cu = [0] + list(np.cumsum(lens))
+    want = ops_ref.attention_varlen(q.view(B, H, D), kv[:, :Hkv * D].view(T, Hkv, D), kv[:, Hkv * D:].view(T, Hkv, D),
+                                    torch.arange(B + 1), cu, D ** -0.5)
+    out = torch.zeros((B, H * D), dtype=dtype, device=gpu_device)
+    ws = nat.Workspace(nat.attn_workspace_bytes(B, H, Hkv, D, splits), gpu_device) if splits > 1 else None
+    nat.attn_paged(q.to(gpu_device), H * D, kpool, vpool, bt.to(gpu_device), torch.tensor(lens, dtype=torch.int32).to(gpu_device),
+                   torch.arange(B + 1, dtype=torch.int32, device=gpu_device), out, B, H, Hkv, D, 1, max(lens), D ** -0.5,
+                   splits, ws)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    _close(out.view(B, H, D), want, rtol=tol, atol=tol, what="chunk blocks on one XCD")
+
+
 # ---- elementwise / sampling ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_act_mul_gelu_embedding(nat, gpu_device, dtype):

@@ -39,8 +39,23 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: the block-table reads become scalar loads
     const int col = lane & 15, c = lane >> 4;
     const int qt = blockIdx.x;
-    const int hk = blockIdx.y / a.HCB, hc0 = (blockIdx.y % a.HCB) * CH;  // first 16-head chunk of this block
-    const int b = blockIdx.z / a.NS, split = blockIdx.z % a.NS;
+    int by = blockIdx.y, bz = blockIdx.z;
+    if (a.xcd_remap) {
+        // Several blocks per (sequence, split, kv head) group — one per set of 16-head chunks — read the SAME K/V pages.
+        // Workgroups go to the 8 XCDs round-robin by linear id, each XCD with its own L2: in grid order the chunk blocks of a
+        // group land on different XCDs and every one of them pulls the pages from HBM.  Remapped, XCD x runs the blocks
+        // x, x + 8, x + 16, ... and consecutive ones of them are the chunk blocks of one group: the pages cross the fabric
+        // once and the other chunk blocks hit that XCD's L2 (MQA 48:1 as three one-chunk blocks, B = 32, ctx 4096:
+        // 44 -> 33 us at 4 splits, profiles/r04_mqa_xcd.log).  gridDim.x == 1 and the number of groups is a multiple
+        // of 8 — the launcher checks.
+        const int L = blockIdx.y + gridDim.y * blockIdx.z;
+        const int x = L & 7, i = L >> 3;
+        const int grp = x + 8 * (i / a.HCB), cb = i % a.HCB;
+        bz = grp / a.Hkv;
+        by = (grp % a.Hkv) * a.HCB + cb;
+    }
+    const int hk = by / a.HCB, hc0 = (by % a.HCB) * CH;  // first 16-head chunk of this block
+    const int b = bz / a.NS, split = bz % a.NS;
 
     const int q0 = a.cu_q[b], q_len = a.cu_q[b + 1] - q0;
     const int t0 = qt * a.TQ;
@@ -235,12 +250,28 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     // pages below kfull are visible in full to every column of the tile (the tile's first token sees kfull keys)
     const int kfull = ctx - q_len + t0 + 1;
     int p = pbeg + w;
+    // The partly visible pages of this wave (decode: the sequence's last page) go FIRST (round 4): the softmax is order-
+    // independent, and their masked body is a second copy of the page code that each wave runs once — at the end of the
+    // launch its instruction fetch and its un-overlapped load were part of every block's tail (ctx 1023 vs 1024: +2.6 us
+    // per launch before, +1.7 after); at the start both hide under the first pages' latency.
+    {
+        const int nfullp = kfull >> 5;  // pages [0, nfullp) are fully visible
+        int pp = p + ((max(nfullp - p, 0) + NW - 1) / NW) * NW;
+        int pgp = (pp < pend) ? btrow[pp] : 0;
+        for (; pp < pend; pp += NW) {
+            const int pg_next = (pp + NW < pend) ? btrow[pp + NW] : 0;
+            V8 kf[2][KS], vf[NB];
+            load_page(pgp, kf, vf);
+            apply_page(pp, kf, vf, std::false_type{});
+            pgp = pg_next;
+        }
+    }
     if (PIPE) {
         // Pairs of fully visible pages with two pages of loads in flight: the next page's 16 KiB are requested before
         // the current page is applied.  The body is straight-line (every load it issues is needed, the trip count is
         // wave-uniform) so that hipcc keeps counted vmcnt waits; with a conditional prefetch it drains to vmcnt(0)
-        // before every load and nothing overlaps (measured: no gain).  What is left — an odd full page, the
-        // partly visible last page — takes the plain loop below.
+        // before every load and nothing overlaps (measured: no gain).  What is left — an odd full page — takes the plain
+        // loop below (the partly visible pages ran first).
         const int nfull = (kfull >> 5) > p ? min(((kfull >> 5) - p + NW - 1) / NW, (pend - p + NW - 1) / NW) : 0;
         const int npairs = p < pend ? nfull >> 1 : 0;
         if (npairs > 0) {
@@ -259,22 +290,15 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
             p += 2 * NW;
         }
     }
-    // fully visible pages first, then the partly visible ones (decode: the last page) — two loops, not one loop with
-    // both bodies: the register allocator sizes a loop for the union of what its branches hold (180 vs 122 VGPRs here,
-    // i.e. 2 instead of 3 waves per SIMD, which costs the HBM-bound many-block shapes 5 %)
+    // the fully visible pages — a loop of their own, not one loop with both bodies: the register allocator sizes a loop
+    // for the union of what its branches hold (180 vs 122 VGPRs here, i.e. 2 instead of 3 waves per SIMD, which costs
+    // the HBM-bound many-block shapes 5 %)
     int pg = (p < pend) ? btrow[p] : 0;
     for (; p < pend && p * 32 + 32 <= kfull; p += NW) {
         const int pg_next = (p + NW < pend) ? btrow[p + NW] : 0;
         V8 kf[2][KS], vf[NB];
         load_page(pg, kf, vf);
         apply_page(p, kf, vf, std::true_type{});
-        pg = pg_next;
-    }
-    for (; p < pend; p += NW) {
-        const int pg_next = (p + NW < pend) ? btrow[p + NW] : 0;
-        V8 kf[2][KS], vf[NB];
-        load_page(pg, kf, vf);
-        apply_page(p, kf, vf, std::false_type{});
         pg = pg_next;
     }
 
@@ -296,7 +320,7 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
         }
     }
     __syncthreads();
-    const int grp = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * b);  // the NS blocks that share their columns
+    const int grp = blockIdx.x + gridDim.x * (by + gridDim.y * b);  // the NS blocks that share their columns
     __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.ws_o, 0, 0x7FFFFFFF, 0x00020000);
     __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.ws_ml, 0, 0x7FFFFFFF, 0x00020000);
     // thread -> (chunk, column j, 8 consecutive d)
@@ -753,6 +777,10 @@ static int attn_paged_impl(const void* q, int64_t ld_q, const void* k_pool, cons
     TGIS_CHECK_ARG(q_tiles <= 2147483647LL && (int64_t)Hkv * a.HCB <= 65535 && B * num_splits <= 65535,
                    "tgis_attn_paged: grid too large");
     dim3 grid((unsigned)q_tiles, (unsigned)(Hkv * a.HCB), (unsigned)(B * num_splits));
+    {
+        static const bool xcd_off = getenv("TGIS_ATTN_XCD") && atoi(getenv("TGIS_ATTN_XCD")) == 0;  // A/B hook
+        a.xcd_remap = (!xcd_off && max_q_len == 1 && q_tiles == 1 && a.HCB > 1 && (B * num_splits * Hkv) % 8 == 0) ? 1 : 0;
+    }
     // waves per block: with >= 1024 (sequence, kv head) blocks the chip is full either way and 2-wave blocks halve
     // the page-count imbalance between a block's waves (33 pages over 4 waves = 9/8/8/8; over 2 = 17/16)
     const int64_t nblocks = (int64_t)grid.x * grid.y * grid.z;

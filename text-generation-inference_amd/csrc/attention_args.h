@@ -15,6 +15,7 @@ struct AttnArgs {
     int out_frag;  // 1: out is [<= 32 tokens, H * D] in 32-row fragment order (xf_off in common.h), else row-major
     int H, Hkv, G, Gc, Gp, TQ, HC, NS;
     int HCB;  // decode kernel: blocks per kv head along the 16-head chunks (HC / chunks per block)
+    int xcd_remap;  // decode kernel, HCB > 1: the chunk blocks of a (sequence, split, kv head) group run on one XCD
     float scale_log2;
     float* ws_o;   // [total_q][H][NS][D]        (fused combine: [group][chunk][16 columns][NS][D])
     float* ws_ml;  // [total_q][H][NS][2]        (fused combine: [group][chunk][16 columns][NS][4], {m, l, -, -})
