@@ -15,6 +15,7 @@
 //   O^T[d][col]  += V^T[d][tok] . P^T[tok][col] A = V^T fragment (1 KiB contiguous loads), B = P^T
 // S^T's accumulator layout IS the B-operand layout of the second MFMA and O^T's column index is the
 // same lane, so the only cross-lane traffic per page is the 2-step row-max exchange.
+#include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
@@ -644,8 +645,11 @@ constexpr int ATTN_COUNTER_SETS = 4;
 struct CounterPool {
     unsigned* sets[ATTN_COUNTER_SETS] = {};
     hipStream_t owner[ATTN_COUNTER_SETS] = {};
+    uint64_t last_use[ATTN_COUNTER_SETS] = {};  // launch stamp: the least recently used slot is handed to a new stream
+    uint64_t stamp = 0;
     int used = 0;
     bool ready = false;
+    bool warned = false;
 };
 std::mutex g_attn_counters_mu;
 std::map<int, CounterPool> g_attn_counters;
@@ -673,11 +677,37 @@ unsigned* attn_counters(hipStream_t st) {
         for (int i = 0; i < ATTN_COUNTER_SETS; ++i) pool.sets[i] = p + (size_t)i * ATTN_COUNTERS;
         pool.ready = true;
     }
+    ++pool.stamp;
     for (int i = 0; i < pool.used; ++i)
-        if (pool.owner[i] == st) return pool.sets[i];
-    if (pool.used == ATTN_COUNTER_SETS) return nullptr;
-    pool.owner[pool.used] = st;
-    return pool.sets[pool.used++];
+        if (pool.owner[i] == st) {
+            pool.last_use[i] = pool.stamp;
+            return pool.sets[i];
+        }
+    if (pool.used < ATTN_COUNTER_SETS) {
+        pool.owner[pool.used] = st;
+        pool.last_use[pool.used] = pool.stamp;
+        return pool.sets[pool.used++];
+    }
+    // All slots are owned.  A slot whose stream has no launch in flight can change hands (its counters are zero between
+    // launches): take the least recently used one if its stream is idle (hipStreamQuery on a destroyed or capturing stream
+    // fails — then the slot stays put and this launch uses the separate combine kernel, which is always correct).
+    int lru = 0;
+    for (int i = 1; i < ATTN_COUNTER_SETS; ++i)
+        if (pool.last_use[i] < pool.last_use[lru]) lru = i;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    if (!capturing && hipStreamQuery(pool.owner[lru]) == hipSuccess) {
+        pool.owner[lru] = st;
+        pool.last_use[lru] = pool.stamp;
+        return pool.sets[lru];
+    }
+    (void)hipGetLastError();
+    if (!pool.warned) {
+        pool.warned = true;
+        fprintf(stderr, "tgis_attn_paged: more than %d streams use split-key decode attention on device %d; the extra ones "
+                        "merge their splits with a second launch\n", ATTN_COUNTER_SETS, dev);
+    }
+    return nullptr;
 }
 }  // namespace
 

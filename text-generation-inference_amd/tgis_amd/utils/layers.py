@@ -72,9 +72,14 @@ class FastLinear:
         """Set by FlashLlamaAttention on the fused qkv projection: (H, Hkv, D) of this shard.  Builds the rope image (a
         second copy of the weight with rotation pairs inside each tile) for native.dense_gemm_rope."""
         self._rope_heads = heads
+        self.rope_handle = None
         if heads is not None and FUSED_ROPE_GEMM and heads[2] % 32 == 0:
             H, Hkv, D = heads
-            self.rope_handle = native.DenseWeight(self.weight, rope=(D, H + Hkv))
+            # the image is a second copy of the weight: only build it where the fused launch will serve some decode batch
+            # (tgis_dense_rope_ok asks for >= TGIS_ROPE_MIN_BLOCKS workgroups in the unsplit plan — TinyLlama has 40, a
+            # 70B shard at TP = 8 has 20), as Ex4bitLinearV2.post_init does for the int4 image
+            if any(native.rope_gemm_ok(m, self.prepared, D) for m in (1, 32, 64)):
+                self.rope_handle = native.DenseWeight(self.weight, rope=(D, H + Hkv))
 
     def forward(self, x: torch.Tensor, act: int = 0, out_f32: bool = False, partial: bool = False,
                 gelu: Optional[bool] = None) -> torch.Tensor:

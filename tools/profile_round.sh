@@ -55,12 +55,12 @@ def gemm_counter(dirname, name):
     vals = []
     for f in glob.glob(out + f"/{dirname}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "gptq_gemm_kernel<" in r["Kernel_Name"] and r["Counter_Name"] == name:
+            if ("gptq_gemm_kernel<" in r["Kernel_Name"] or "gptq_wide_kernel<" in r["Kernel_Name"]) and r["Counter_Name"] == name:
                 vals.append(float(r["Counter_Value"]))
     return vals
 gf, gw = gemm_counter("prof_fetch", "FETCH_SIZE"), gemm_counter("prof_write", "WRITE_SIZE")
 if gf:
-    resg = {"kernel": "gptq_gemm_kernel (all decode launches: qkv, o_proj, gate_up, down)", "launches": len(gf),
+    resg = {"kernel": "gptq_wide_kernel / gptq_gemm_kernel (all decode launches: qkv + rotary, o_proj, gate_up + SiLU, down)", "launches": len(gf),
             "FETCH_SIZE_KB_per_launch_raw": sum(gf) / len(gf),
             "WRITE_SIZE_KB_per_launch_raw": (sum(gw) / len(gw)) if gw else None,
             "fetch_bytes_per_launch_corrected": sum(gf) / len(gf) * 1024 * 2,
