@@ -604,7 +604,7 @@ extern "C" int64_t tgis_gptq_gemm_fused_rows(int64_t K, int64_t groups, int act_
 extern "C" int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N) {
     GemmPlan pl = plan_gemm(K, N, 0, M);
     int64_t need = 4096 + slab_bytes(M, N, pl.S);
-    if (M <= 64 && K % 64 == 0) need = std::max(need, 4096 + slab_bytes(M, N, gptq::plan_wide(K, N, 0).S));
+    if (M <= 64 && K % 64 == 0) need = std::max(need, 4096 + slab_bytes(M, N, gptq::wide_max_splits(K, N)));
     if (M >= tall_min_m() && K % 64 == 0) need = std::max(need, 4096 + tall_slab_bytes(M, N, plan_tall(M, K, N, 0).S));
     return need;
 }
@@ -654,7 +654,7 @@ struct RopeEpi {
 
 template <int CT, int ACT, bool OUTF, int MR>
 static int launch_wide_mr(dim3 grid, hipStream_t st, const GemmArgs& a) {
-    constexpr size_t lds = (size_t)gptq::WIDE_WK * CT * 4096;
+    const size_t lds = gptq::wide_lds_bytes(CT);
     static bool attr_done = false;
     if (!attr_done) {
         TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_wide_kernel<CT, ACT, OUTF, MR>,
@@ -827,8 +827,8 @@ static int check_gemm_args(const void* x, int64_t ldx, const void* prepared, int
 }
 
 // the fragment-order kernel's plan in the GemmPlan that launch_gptq takes (TN = column tiles per wave, S = k splits)
-static GemmPlan wide_plan_as_gemm_plan(int64_t K, int64_t N, int act) {
-    const gptq::WidePlan w = gptq::plan_wide(K, N, act);
+static GemmPlan wide_plan_as_gemm_plan(int64_t K, int64_t N, int act, int64_t M) {
+    const gptq::WidePlan w = gptq::plan_wide(K, N, act, M);
     return {0, w.S, gptq::WIDE_WK, w.CT, 1};
 }
 
@@ -845,7 +845,7 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
         TGIS_CHECK_ARG(!perm, "tgis_gptq_gemm_f16: act-order matrices take a row-major activation");
         TGIS_CHECK_ARG(ldo != TGIS_LD_FRAGMENTS || (act == 2 && (N / 2) % 64 == 0),
                        "tgis_gptq_gemm_f16: only the act = 2 output (N / 2 a multiple of 64) can leave in fragment order");
-        const GemmPlan wp = wide_plan_as_gemm_plan(K, N, act);
+        const GemmPlan wp = wide_plan_as_gemm_plan(K, N, act, M);
         const int64_t need_w = 4096 + slab_bytes(M, N, wp.S);
         TGIS_CHECK_ARG(workspace && workspace_bytes >= need_w, "tgis_gptq_gemm_f16: workspace too small (%ld < %ld)",
                        (long)workspace_bytes, (long)need_w);
@@ -928,7 +928,7 @@ extern "C" int tgis_gptq_gemm_rope_f16(const void* x, int64_t ldx, const void* p
     TGIS_CHECK_ARG(H >= 1 && Hkv >= 1 && (H + 2 * Hkv) * D == N && ldq >= H * D,
                    "tgis_gptq_gemm_rope_f16: N must be (H + 2 Hkv) * D and q rows must hold H * D elements");
     GemmPlan pl = plan_gemm(K, N, 2, M);  // as the SiLU epilogue: the whole k range in one block (S == 1)
-    if (ldx == TGIS_LD_FRAGMENTS) pl = wide_plan_as_gemm_plan(K, N, 3);
+    if (ldx == TGIS_LD_FRAGMENTS) pl = wide_plan_as_gemm_plan(K, N, 3, M);
     RopeEpi rope{positions, slots, (const f16*)cos, (const f16*)sin, (f16*)k_pool, (f16*)v_pool, (int)H, (int)Hkv, (int)D};
     hipStream_t st = (hipStream_t)stream;
     TgisTimedScope timed(TGIS_OP_GPTQ_GEMM, st);
@@ -1078,7 +1078,7 @@ extern "C" int64_t tgis_gptq_gemm_partial_bytes(int64_t M, int64_t K, int64_t N)
     GemmPlan pl = plan_gemm(K, N, 0, M);
     int64_t need = cdiv64(std::max<int64_t>(M, 1), 64) * 2 * pl.S * 32 * cdiv64(N, 32) * 32 * 4;
     if (M <= 64 && K % 64 == 0)  // the fragment-order kernel's plan may split further
-        need = std::max<int64_t>(need, (int64_t)2 * gptq::plan_wide(K, N, 0).S * 32 * cdiv64(N, 32) * 32 * 4);
+        need = std::max<int64_t>(need, (int64_t)2 * gptq::wide_max_splits(K, N) * 32 * cdiv64(N, 32) * 32 * 4);
     if (M >= tall_min_m() && K % 64 == 0) need = std::max(need, tall_slab_bytes(M, N, plan_tall(M, K, N, 0).S));
     return need;
 }
@@ -1093,7 +1093,7 @@ extern "C" int tgis_gptq_fragments_ok(int64_t M, int64_t K, int64_t N, int64_t g
     static const int64_t max_rows = getenv("TGIS_GPTQ_FRAGMENTS_MAX_ROWS") ? atoll(getenv("TGIS_GPTQ_FRAGMENTS_MAX_ROWS")) : 64;
     if (M > max_rows) return 0;
     static const int64_t min_blocks = getenv("TGIS_ROPE_MIN_BLOCKS") ? atoll(getenv("TGIS_ROPE_MIN_BLOCKS")) : 128;
-    if ((act == 2 || act == 3) && gptq::wide_blocks(K, N, act) < min_blocks) return 0;
+    if ((act == 2 || act == 3) && gptq::wide_blocks(K, N, act, M) < min_blocks) return 0;
     return 1;
 }
 
@@ -1116,7 +1116,7 @@ extern "C" int tgis_gptq_gemm_f16_partial(const void* x, int64_t ldx, const void
     GemmPlan pl = plan_gemm(K, N, 0, M);
     if (ldx == TGIS_LD_FRAGMENTS) {
         TGIS_CHECK_ARG(!perm && act == 0, "tgis_gptq_gemm_f16_partial: fragment-order activations: act 0, no act-order");
-        pl = wide_plan_as_gemm_plan(K, N, 0);
+        pl = wide_plan_as_gemm_plan(K, N, 0, M);
     }
     TGIS_CHECK_ARG(slabs && slabs_bytes >= tgis_gptq_gemm_partial_bytes(M, K, N),
                    "tgis_gptq_gemm_f16_partial: slab buffer too small");

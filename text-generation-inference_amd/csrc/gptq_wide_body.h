@@ -20,10 +20,17 @@
 #pragma once
 #include "gptq_gemm_body.h"
 
+// tools/floor/wide_unit.hip compiles this unit with WIDE_STAMP defined (s_memtime stamps per wave); the library does not.
+#ifndef WIDE_STAMP
+#define WIDE_STAMP(i)
+#endif
+
 namespace gptq {
 
 constexpr int WIDE_WK = 8;      // k-parts (waves) per block
 constexpr int WIDE_DEPTH = 2;   // k64-steps in flight per wave
+constexpr int WIDE_TG(int ct) { return ct < 4 ? ct : 4; }   // tiles per round of the k-part exchange
+static inline size_t wide_lds_bytes(int ct) { return (size_t)WIDE_WK * WIDE_TG(ct) * 4096; }
 
 struct WidePlan {
     int CT, S;  // column tiles per wave (= per block), global k splits
@@ -43,7 +50,7 @@ static inline bool wide_serves(int64_t M, int64_t K, int64_t N, int64_t groups, 
 // One block per CU where the shape allows it: column groups first (a wider group re-uses an A fragment more often), then
 // global k splits (fp32 slabs that the consumer sums) until ~256 blocks; at least one k64-step per wave.
 // act 2 / 3 (SiLU * up, rotary + cache write) finish their outputs in the epilogue: no split.
-static inline WidePlan plan_wide(int64_t K, int64_t N, int act) {
+static inline WidePlan plan_wide(int64_t K, int64_t N, int act, int64_t M = 32) {
     if (const char* ov = getenv("TGIS_GPTQ_WIDE_PLAN")) {  // tuning hook: "CT,S"
         int ct = 0, sp = 0;
         if (sscanf(ov, "%d,%d", &ct, &sp) == 2 && ct >= 2 && ct <= 4 && sp >= 1 && (sp == 1 || (act != 2 && act != 3)))
@@ -58,13 +65,22 @@ static inline WidePlan plan_wide(int64_t K, int64_t N, int act) {
         S = std::max<int64_t>(1, (256 + cgs / 2) / cgs);
         S = std::min<int64_t>(S, std::max<int64_t>(1, steps / WIDE_WK));
         while (S > 1 && (S - 1) * cdiv64(steps, S) >= steps) --S;  // no empty last split
+        // 64 rows: the activation is 8 KiB per k64-step against CT KiB of weights — with a long k range four tiles per wave
+        // and twice the splits move half the activation bytes per weight byte (70B down projection 47 -> 41 us; shorter
+        // ranges lose more to the extra slabs: 70B o 17.4 vs 18.9, 7B down 14.2 vs 15.5 — tools/floor/wide_unit.hip)
+        if (M > 32 && CT == 2 && tiles % 4 == 0 && steps / (WIDE_WK * 2 * S) >= 12) {
+            CT = 4;
+            S *= 2;
+        }
     }
     return {CT, (int)S};
 }
-static inline int64_t wide_blocks(int64_t K, int64_t N, int act) {
-    const WidePlan p = plan_wide(K, N, act);
+static inline int64_t wide_blocks(int64_t K, int64_t N, int act, int64_t M = 32) {
+    const WidePlan p = plan_wide(K, N, act, M);
     return cdiv64(cdiv64(N, 32), p.CT) * p.S;
 }
+// the largest split count either row class (<= 32, <= 64) may use: what slab buffers are sized for
+static inline int wide_max_splits(int64_t K, int64_t N) { return std::max(plan_wide(K, N, 0, 32).S, plan_wide(K, N, 0, 64).S); }
 
 // OUTF: the act = 2 output (the operand of the down projection) leaves in fragment order as well.
 // MR = 32-row blocks of the activation (1: M <= 32; 2: M <= 64 — every dequantised B fragment then feeds two MFMAs, the
@@ -149,8 +165,10 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
 #pragma unroll
         for (int t = 0; t < CT; ++t) acc[mr][t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
+    WIDE_STAMP(0);
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) load_step(d, s0 + d);
+    WIDE_STAMP(1);
 
     auto consume = [&](int d) {
 #pragma unroll
@@ -178,10 +196,12 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    WIDE_STAMP(2);
     // the last group: only the steps that exist (wave-uniform branches; nothing is requested any more)
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
         if (s + d < s1) consume(d);
+    WIDE_STAMP(3);
 
     // ACT 3: the finishing rows' cos / sin entries are requested before the exchange (their positions came in at entry)
     f16 rcos[ACT == 3 ? MR : 1][ACT == 3 ? CT : 1][ACT == 3 ? NR : 1], rsin[ACT == 3 ? MR : 1][ACT == 3 ? CT : 1][ACT == 3 ? NR : 1];
@@ -207,28 +227,32 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
     // words), then wave wk sums registers [wk NR, (wk + 1) NR) of every tile in the fixed order of the k-parts ----
     float* red = reinterpret_cast<float*>(smem);
     const int c = lane & 31;
+    // (CT > 4: the tiles meet in groups of TG = 4, so that the scratch stays at WK x 4 x 4 KiB = 128 KiB)
+    constexpr int TG = WIDE_TG(CT);
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
-        if (mr > 0) __syncthreads();  // the previous row block's sums have been read
 #pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            float* dst = red + ((wk * CT + t) << 10) + lane;
+      for (int tg0 = 0; tg0 < CT; tg0 += TG) {
+        if (mr > 0 || tg0 > 0) __syncthreads();  // the previous group's sums have been read
+#pragma unroll
+        for (int t = tg0; t < tg0 + TG && t < CT; ++t) {
+            float* dst = red + ((wk * TG + (t - tg0)) << 10) + lane;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dst[r << 6] = acc[mr][t][r];
         }
         __syncthreads();
         float fin[CT][NR];
 #pragma unroll
-        for (int t = 0; t < CT; ++t) {
+        for (int t = tg0; t < tg0 + TG && t < CT; ++t) {
 #pragma unroll
             for (int k2 = 0; k2 < WK; ++k2) {
-                const float* src = red + ((k2 * CT + t) << 10) + ((wk * NR) << 6) + lane;
+                const float* src = red + ((k2 * TG + (t - tg0)) << 10) + ((wk * NR) << 6) + lane;
 #pragma unroll
                 for (int j = 0; j < NR; ++j) fin[t][j] = k2 == 0 ? src[j << 6] : fin[t][j] + src[j << 6];
             }
         }
 #pragma unroll
-        for (int t = 0; t < CT; ++t) {
+        for (int t = tg0; t < tg0 + TG && t < CT; ++t) {
             const int nt = cg * CT + t;
             if (nt >= a.NT) break;
             if (ACT == 3) {
@@ -303,7 +327,9 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
                 for (int j = 0; j < NR; ++j) sl[(int64_t)(row_of(mr, j) & 31) * (a.NT * 32)] = fin[t][j];
             }
         }
+      }
     }
+    WIDE_STAMP(4);
 }
 
 }  // namespace gptq
