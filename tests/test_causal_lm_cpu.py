@@ -291,3 +291,125 @@ def test_servicer_runs_the_padded_batch_type(lm):
             await server.stop(0)
 
     asyncio.run(run())
+
+
+# ---- the reference's other KV-cache layouts (causal_lm.py:742-756) -------------------------------------------------------
+class _LayoutAdapter(torch.nn.Module):
+    """The SAME tiny GPT-2, speaking one of the pre-4.4x cache layouts at its boundary: `bloom` = keys
+    [B * heads, head_dim, T], values [B * heads, T, head_dim]; `merged` = one [B, T, 2 * heads * head_dim] tensor per
+    layer.  What goes in and out of the wrapped model is the standard layout, so the logits are those of the fixtures."""
+
+    def __init__(self, hf, kind, to_lib, from_lib):
+        super().__init__()
+        self.hf, self.kind, self.config = hf, kind, hf.config
+        self._to_lib, self._from_lib = to_lib, from_lib
+        self.heads = hf.config.n_head
+
+    def _standard(self, past, B):
+        out = []
+        for layer in past:
+            if self.kind == "merged":
+                T = layer.shape[1]
+                k, v = layer.view(B, T, 2, self.heads, -1).unbind(2)
+                out.append([k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)])
+            else:
+                k, v = layer
+                D, T = k.shape[-2:]
+                out.append([k.view(B, self.heads, D, T).permute(0, 1, 3, 2), v.view(B, self.heads, T, D)])
+        return out
+
+    def _native(self, past):
+        out = []
+        for k, v in past:
+            B, H, T, D = k.shape
+            if self.kind == "merged":
+                out.append(torch.stack([k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)], dim=2).reshape(B, T, 2 * H * D))
+            else:
+                out.append((k.permute(0, 1, 3, 2).reshape(B * H, D, T), v.reshape(B * H, T, D)))
+        return tuple(out)
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, use_cache=True,
+                return_dict=True, inputs_embeds=None):
+        B = (input_ids if input_ids is not None else inputs_embeds).shape[0]
+        past = None if past_key_values is None else self._to_lib([[k.contiguous(), v.contiguous()]
+                                                                  for k, v in self._standard(past_key_values, B)])
+        kw = dict(attention_mask=attention_mask, position_ids=position_ids, past_key_values=past, use_cache=True,
+                  return_dict=True)
+        kw["input_ids" if inputs_embeds is None else "inputs_embeds"] = input_ids if inputs_embeds is None else inputs_embeds
+        out = self.hf(**kw)
+        out.past_key_values = self._native(self._from_lib(out.past_key_values))
+        return out
+
+
+@pytest.mark.parametrize("kind", ["bloom", "merged"])
+def test_continuous_batching_on_the_older_kv_layouts(lm, kind):
+    """`KeysDimTransposedCausalLMBatch` / `CombinedKVCausalLMBatch`: the continuous-batching scenario of the reference
+    fixture (prefill, decode, prefill-for-concat, concatenate, decode, prune, decode) with the model's cache in the BLOOM
+    or the merged multi-query layout.  Same model, same inputs: batch tensors bit for bit and tokens / logits as the
+    fixture captured from the reference."""
+    from tgis_amd.inference_engine.hf_transformers import InferenceEngine
+    from tgis_amd.models import causal_lm as clm
+
+    std = clm.CausalLM._to_library_cache.__get__(lm)  # the standard-layout conversion of the fixture model
+    adapter = _LayoutAdapter(lm.model, kind, std, clm.CausalLM._from_library_cache)
+    eng = InferenceEngine(None, None, torch.float32, None, None, 128, preloaded=adapter, tokenizer=lm.tokenizer)
+    alt = clm.CausalLM("gpt2-tiny-" + kind, None, "hf_transformers", torch.float32, None, engine=eng)
+    want_type = clm.CombinedKVCausalLMBatch if kind == "merged" else clm.KeysDimTransposedCausalLMBatch
+    assert alt.batch_type is want_type and alt.use_position_ids
+    meta, steps = load_fixture("gpt2_continuous")
+    extra = _extra("gpt2_continuous")
+    tap = _Tap(alt)
+    try:
+        a = _from_pb(alt, _requests(meta["prompts_a"], meta["max_new_a"], first_id=0, batch_id=1))
+        assert isinstance(a, want_type) and a.merged_kv_cache == (kind == "merged") and a.keys_head_dim_last == (kind != "bloom")
+        got = [_step(alt, tap, a, first=True), _step(alt, tap, a), _step(alt, tap, a)]
+        b = _from_pb(alt, _requests(meta["prompts_b"], meta["max_new_b"], first_id=2, batch_id=2))
+        got.append(_step(alt, tap, b, first=True, for_concat=True))
+        with alt.context_manager():
+            merged = alt.batch_type.concatenate([a, b])
+        _same_state(merged, extra, "merged")
+        layer0 = merged.past_key_values[0]
+        past = merged.max_sequence_length - 1
+        if kind == "merged":
+            assert torch.is_tensor(layer0) and layer0.shape[:2] == (3, past)
+        else:
+            H = lm.model.config.n_head
+            assert layer0[0].dim() == 3 and layer0[0].shape[0] == 3 * H and layer0[0].shape[2] == past
+            assert layer0[1].shape[:2] == (3 * H, past)
+        got += [_step(alt, tap, merged), _step(alt, tap, merged)]
+        with alt.context_manager():
+            merged = alt.batch_type.prune(merged, [2])
+        _same_state(merged, extra, "pruned")
+        got += [_step(alt, tap, merged), _step(alt, tap, merged)]
+        _same_state(merged, extra, "final")
+    finally:
+        tap.close()
+    for i, ((toks, _, logits), want) in enumerate(zip(got, steps)):
+        _same_tokens(toks, logits, want, f"{kind} layout, continuous step {i}")
+
+
+def test_kv_layout_time_axis_operations():
+    """KVLayout's primitives on synthetic caches of the three layouts: the last n positions, the per-row view of flattened
+    heads and the way back — what concatenate / prune / the pad-to-8 trim of a CUDA prefill are built from."""
+    from tgis_amd.models.causal_lm import KVLayout
+
+    B, H, T, D = 3, 2, 7, 4
+    k = torch.arange(B * H * T * D, dtype=torch.float32).view(B, H, T, D)
+    v = -k
+    std, bloom, merged = KVLayout(), KVLayout(keys_time_last=True), KVLayout(merged=True)
+    assert KVLayout.probe([[k, v]]) == std
+    kb, vb = k.permute(0, 1, 3, 2).reshape(B * H, D, T), v.reshape(B * H, T, D)
+    assert KVLayout.probe([[kb, vb]]) == bloom
+    m = torch.cat([k.permute(0, 2, 1, 3).reshape(B, T, H * D), v.permute(0, 2, 1, 3).reshape(B, T, H * D)], dim=-1)
+    assert KVLayout.probe([m]) == merged
+    n = 3
+    assert torch.equal(std.last(0, k, n), k[:, :, T - n:, :]) and torch.equal(std.last(1, v, n), v[:, :, T - n:, :])
+    assert torch.equal(bloom.last(0, kb, n), kb[:, :, T - n:]) and torch.equal(bloom.last(1, vb, n), vb[:, T - n:, :])
+    assert torch.equal(merged.last(0, m, n), m[:, T - n:, :])
+    keep = [0, 2]
+    rows = bloom.by_row(kb, B)
+    assert rows.shape == (B, H, D, T)
+    back = bloom.like(bloom.last(0, rows[keep], n), kb)
+    assert back.shape == (len(keep) * H, D, n)
+    assert torch.equal(back.view(len(keep), H, D, n).permute(0, 1, 3, 2), k[keep][:, :, T - n:, :])
+    assert merged.by_row(m, B) is m and merged.slots(m) == [m] and merged.pack([m]) is m

@@ -17,9 +17,12 @@ Geometry every method below relies on — a batch is a right-aligned window with
 Every step moves the boundary one column to the right (`max_sequence_length += 1`, `padding_right_offset -= 1`).
 All slicing is done with explicit column indices computed from those two numbers.
 
-Only the standard KV layout `[B, heads, T, head_dim]` for both keys and values is handled (GPT-2, Llama, GPT-BigCode
-under transformers >= 4.4x); the reference's BLOOM (transposed keys) and merged-KV GPT-BigCode variants
-(:742-756) belong to model families / library versions outside BASELINE.json's configs."""
+KV layouts (`KVLayout`): the standard `[B, heads, T, head_dim]` pair per layer (GPT-2, Llama, GPT-BigCode under
+transformers >= 4.4x), the BLOOM-era pair with flattened heads and transposed keys (`[B * heads, head_dim, T]` /
+`[B * heads, T, head_dim]`: `KeysDimTransposedCausalLMBatch`, reference :742-748) and the merged multi-query tensor
+`[B, T, C]` of older GPT-BigCode (`CombinedKVCausalLMBatch`, :750-756).  Every membership operation below touches the
+cache only through the layout's time axis, so the three share one code path (the reference branches per layout:
+:337-442, :504-509, :528-545, :722-729)."""
 import inspect
 import logging
 import os
@@ -38,7 +41,51 @@ from tgis_amd.utils.tokens import HeterogeneousNextTokenChooser, get_input_token
 # prefill windows on CUDA are padded on the left to a multiple of 8 columns (models/model.py:24-25 of the reference)
 CUDA_PAD_TO_MULT_OF_8 = os.getenv("CUDA_PAD_TO_MULT_OF_8", "true").lower() != "false"
 
-KVLayers = List[List[torch.Tensor]]  # per layer [keys, values], each [B, heads, T, head_dim]
+KVLayers = List[Any]  # per layer [keys, values] (each [B, heads, T, head_dim], see KVLayout) or one merged tensor
+
+
+@dataclass(frozen=True)
+class KVLayout:
+    """How the library model lays out one layer of its cache (the reference's `keys_head_dim_last` / `merged_kv_cache`
+    batch flags, causal_lm.py:54-57, and its `three_dim_pkvs` shape test, :253)."""
+    merged: bool = False          # one tensor [B, T, C] per layer instead of a [keys, values] pair
+    keys_time_last: bool = False  # keys end in [head_dim, T] instead of [T, head_dim]
+
+    @staticmethod
+    def probe(past: KVLayers) -> "KVLayout":
+        """From the cache of a one-token forward (:582-586)."""
+        if torch.is_tensor(past[0]):
+            return KVLayout(merged=True)
+        k, v = past[0]
+        return KVLayout(keys_time_last=k.shape[-1] != v.shape[-1])
+
+    def slots(self, layer) -> List[torch.Tensor]:
+        return [layer] if self.merged else [layer[0], layer[1]]
+
+    def pack(self, tensors: List[torch.Tensor]):
+        return tensors[0] if self.merged else tensors
+
+    def time_axis(self, slot: int, t: torch.Tensor) -> int:
+        if self.merged:
+            return 1
+        return t.dim() - 1 if (slot == 0 and self.keys_time_last) else t.dim() - 2
+
+    def by_row(self, t: torch.Tensor, rows: int) -> torch.Tensor:
+        """A view whose first axis is the batch row (flattened `[B * heads, ., .]` tensors get their head axis back)."""
+        if not self.merged and t.dim() == 3:
+            return t.view(rows, -1, *t.shape[-2:])
+        return t
+
+    def like(self, t4: torch.Tensor, proto: torch.Tensor) -> torch.Tensor:
+        """Back to the model's own rank (`[B * heads, ., .]` if that is what it produced)."""
+        if not self.merged and proto.dim() == 3:
+            return t4.reshape(-1, *t4.shape[-2:])
+        return t4
+
+    def last(self, slot: int, t: torch.Tensor, n: int) -> torch.Tensor:
+        """The last `n` cache positions."""
+        ax = self.time_axis(slot, t)
+        return t.narrow(ax, t.shape[ax] - n, n)
 
 
 def _right_aligned(dst: torch.Tensor, rows: slice, src: torch.Tensor, right_edge: int) -> None:
@@ -67,6 +114,16 @@ class CausalLMBatch(Batch):
     padding_right_offset: int
     max_remaining_tokens: List[int]
     pad_token_id: int
+    kv_layout: KVLayout = KVLayout()
+
+    # the reference's names for the two layout flags (causal_lm.py:54-57)
+    @property
+    def keys_head_dim_last(self) -> bool:
+        return not self.kv_layout.keys_time_last
+
+    @property
+    def merged_kv_cache(self) -> bool:
+        return self.kv_layout.merged
 
     def get_id(self) -> int:
         return self.batch_id
@@ -198,22 +255,28 @@ class CausalLMBatch(Batch):
             return_logprobs.extend(b.next_token_chooser.return_logprobs)
             row += len(b)
 
-        # KV: one zero-filled [B, heads, tokens - 1, head_dim] pair per layer, each source's past right-aligned in it
+        # KV: per layer and tensor one zero-filled block with tokens - 1 positions on its time axis, each source's past
+        # right-aligned in it (whatever the layout: KVLayout names the axis)
+        lay = head.kv_layout
         merged_kv: KVLayers = []
         for layer in range(len(head.past_key_values)):
-            pair = []
-            for which in (0, 1):
-                proto = head.past_key_values[layer][which]
-                out = proto.new_zeros((B, proto.shape[1], tokens - 1, proto.shape[3]))
+            outs = []
+            for slot, proto in enumerate(lay.slots(head.past_key_values[layer])):
+                p4 = lay.by_row(proto, len(head))
+                ax = lay.time_axis(slot, p4)
+                shape = list(p4.shape)
+                shape[0], shape[ax] = B, tokens - 1
+                out = proto.new_zeros(shape)
                 row = 0
                 for b in batches:
-                    src = b.past_key_values[layer][which]
+                    src = lay.by_row(lay.slots(b.past_key_values[layer])[slot], len(b))
                     past = b.max_sequence_length - 1
-                    out[row:row + len(b), :, tokens - 1 - past:, :] = src[:, :, src.shape[2] - past:, :]
-                    b.past_key_values[layer][which] = None  # release the source as soon as it is copied
+                    lay.last(slot, out.narrow(0, row, len(b)), past).copy_(lay.last(slot, src, past))
                     row += len(b)
-                pair.append(out)
-            merged_kv.append(pair)
+                outs.append(lay.like(out, proto))
+            for b in batches:
+                b.past_key_values[layer] = None  # release the source as soon as it is copied
+            merged_kv.append(lay.pack(outs))
 
         ntc0 = head.next_token_chooser
         chooser = HeterogeneousNextTokenChooser.from_pb(
@@ -225,7 +288,7 @@ class CausalLMBatch(Batch):
                    attention_mask=mask, position_ids=position_ids, past_key_values=merged_kv,
                    all_input_ids_tensor=all_ids, input_lengths=input_lengths, next_token_chooser=chooser,
                    max_sequence_length=tokens, padding_right_offset=headroom, max_remaining_tokens=remaining,
-                   pad_token_id=head.pad_token_id)
+                   pad_token_id=head.pad_token_id, kv_layout=lay)
 
     @classmethod
     def prune(cls, batch: "CausalLMBatch", completed_ids: List[int]) -> Optional["CausalLMBatch"]:
@@ -234,6 +297,7 @@ class CausalLMBatch(Batch):
         keep = Model.get_indices_to_keep(batch.requests, completed_ids)
         if not keep:
             return None
+        size_before = len(batch)
         pick = lambda xs: [xs[i] for i in keep]  # noqa: E731
         batch.requests = pick(batch.requests)
         batch.input_lengths = pick(batch.input_lengths)
@@ -250,10 +314,36 @@ class CausalLMBatch(Batch):
         if batch.position_ids is not None:
             batch.position_ids = batch.position_ids[keep]
         past = tokens - 1
-        batch.past_key_values = [[t[keep, :, t.shape[2] - past:, :] for t in layer] for layer in batch.past_key_values]
+        lay = batch.kv_layout
+        batch.past_key_values = [
+            lay.pack([lay.like(lay.last(slot, lay.by_row(t, size_before)[keep], past), t)
+                      for slot, t in enumerate(lay.slots(layer))])
+            for layer in batch.past_key_values]
         batch.max_sequence_length = tokens
         batch.padding_right_offset = headroom
         return batch
+
+
+class KeysDimTransposedCausalLMBatch(CausalLMBatch):
+    """Keys `[.., head_dim, T]` (BLOOM before transformers 4.4x; reference causal_lm.py:742-748)."""
+
+    @classmethod
+    def from_pb(cls, *args, **kwargs):
+        batch, errors = super().from_pb(*args, **kwargs)
+        if batch is not None:
+            batch.kv_layout = KVLayout(keys_time_last=True)
+        return batch, errors
+
+
+class CombinedKVCausalLMBatch(CausalLMBatch):
+    """One merged `[B, T, C]` tensor per layer (multi-query GPT-BigCode before transformers 4.4x; :750-756)."""
+
+    @classmethod
+    def from_pb(cls, *args, **kwargs):
+        batch, errors = super().from_pb(*args, **kwargs)
+        if batch is not None:
+            batch.kv_layout = KVLayout(merged=True)
+        return batch, errors
 
 
 class CausalLM(Model):
@@ -284,23 +374,29 @@ class CausalLM(Model):
             else:
                 tok.add_special_tokens({"pad_token": "[PAD]"})
 
-        # probe the KV layout once: this batch type handles [B, heads, T, head_dim] keys and values only
+        # probe the KV layout once with a one-token forward and pick the batch type for it (:580-586)
+        self.kv_layout = KVLayout()
         one = torch.tensor([[1]], device=self.device)
         _, probe, _ = self.forward(input_ids=one, attention_mask=one)
-        k, v = probe[0]
-        if k.dim() != 4 or k.shape != v.shape:
-            raise NotImplementedError(
-                f"KV cache layout keys {tuple(k.shape)} / values {tuple(v.shape)} is not supported by CausalLMBatch "
-                "(transposed-key and merged-KV model families are outside this build's configs)")
+        self.kv_layout = KVLayout.probe(probe)
+        self._batch_type = (CombinedKVCausalLMBatch if self.kv_layout.merged
+                            else KeysDimTransposedCausalLMBatch if self.kv_layout.keys_time_last else CausalLMBatch)
 
     @property
     def batch_type(self) -> Type[CausalLMBatch]:
-        return CausalLMBatch
+        return self._batch_type
+
+    @batch_type.setter
+    def batch_type(self, value):
+        self._batch_type = value
 
     # ---- library boundary: per-layer [k, v] lists <-> whatever cache object this transformers version wants -------
     def _to_library_cache(self, past: Optional[KVLayers]):
         if past is None:
             return None
+        if self.kv_layout != KVLayout():
+            # pre-4.4x layouts are only produced by models that take the legacy tuples back
+            return tuple(past) if self.kv_layout.merged else tuple((k, v) for k, v in past)
         pairs = [(k, v) for k, v in past]
         try:
             from transformers.cache_utils import DynamicCache
@@ -317,6 +413,8 @@ class CausalLM(Model):
             return [[layer.keys, layer.values] for layer in cache.layers]
         if hasattr(cache, "to_legacy_cache"):
             cache = cache.to_legacy_cache()
+        if torch.is_tensor(cache[0]):  # merged K/V: one tensor per layer
+            return list(cache)
         return [[k, v] for k, v in cache]
 
     def forward(self, input_ids: Optional[torch.Tensor], attention_mask: torch.Tensor,
@@ -373,7 +471,9 @@ class CausalLM(Model):
             align = w_end - batch.max_sequence_length
             if align:  # the pad-to-8 columns of a CUDA prefill are dropped so that the full length stays reachable
                 batch.attention_mask = batch.attention_mask[:, align:]
-                past = [[t[:, :, align:, :] for t in layer] for layer in past]
+                lay = batch.kv_layout
+                past = [lay.pack([lay.last(slot, t, t.shape[lay.time_axis(slot, t)] - align)
+                                  for slot, t in enumerate(lay.slots(layer))]) for layer in past]
 
         if batch.position_ids is not None:
             batch.position_ids = batch.position_ids[:, -1:] + 1
