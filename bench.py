@@ -432,7 +432,8 @@ def main():
             bytes_per_launch = B * ctx_timed_mean * 2 * Hkv_rank * D * 2 + B * 2 * Hkv_rank * D * 2
             avg_s = ms_attn * 1e-3 / max(n_attn, 1)
             achieved = bytes_per_launch / avg_s / 1e9
-            traffic, traffic_src = pmc_traffic(args.config, B, ctx_mean)
+            # the committed counter pass is of the single-GPU workload: a rank of a TP group streams other bytes -> null
+            traffic, traffic_src = pmc_traffic(args.config, B, ctx_mean) if tp == 1 else (None, None)
             roofline = {"bound": "hbm", "kernel": "attn_paged_kernel (decode)", "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": traffic,
@@ -454,7 +455,7 @@ def main():
             if n_gemm:
                 g_avg_s = ms_gemm * 1e-3 / n_gemm
                 g_bytes = gemm_bytes_step / max(per_step, 1)
-                g_traffic, g_traffic_src = pmc_gemm_traffic(args.config, B, ctx_mean)
+                g_traffic, g_traffic_src = pmc_gemm_traffic(args.config, B, ctx_mean) if tp == 1 else (None, None)
                 roofline_gemm = {"bound": "hbm", "kernel": ("gptq_wide_kernel / gptq_gemm_kernel" if quantize == "gptq"
                                                             else "dense_gemm_kernel") + f" ({per_step:.0f} launches per step)",
                                  "achieved": round(g_bytes / g_avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
