@@ -194,6 +194,10 @@ def test_full_width_slice_matches_oracle(gpu_device, name):
 # row-parallel shards regroup 28 groups per rank), one kv head and eight q heads per rank (GQA 8:1) at ctx 2048, B = 64,
 # vocab-parallel embedding and head — and the gathered logits are compared with the unsharded oracle.
 CFG4 = ("cfg4-llama70b-gptq-tp8-b64-ctx2048", LLAMA_70B, 1, "gptq", torch.float16, 64, 2045, 4, 0.03)
+# cfg5 the same way: Starcoder-15B (GPT-BigCode, multi-query) as four ranks — 12 q heads per rank on the replicated kv
+# head, c_attn 6144 x (1536 + 256), attn c_proj 1536 x 6144, c_fc 6144 x 6144, mlp c_proj 6144 x 6144 (bf16), ctx 4096, B = 32
+CFG5 = ("cfg5-starcoder-bf16-tp4-b32-ctx4096", STARCODER, 1, None, torch.bfloat16, 32, 4093, 3, 0.12)
+TP_CASES = {"cfg4": ("llama", CFG4), "cfg5": ("bigcode", CFG5)}
 
 
 def _free_port():
@@ -204,7 +208,7 @@ def _free_port():
     return p
 
 
-def _tp_worker(rank, world, port, ret):
+def _tp_worker(rank, world, port, ret, case="cfg4"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       TGIS_DIST_BACKEND="gloo", TGIS_ALLOW_SHARED_GPU="1", TGIS_DIST_TIMEOUT_S="900")
     import sys
@@ -214,14 +218,14 @@ def _tp_worker(rank, world, port, ret):
         if p not in sys.path:
             sys.path.insert(0, p)
     from tests.fixture_utils import FixtureTokenizer
-    from tests.test_fullwidth_gpu import CFG4, _make, _prompts, _run_product
+    from tests.test_fullwidth_gpu import TP_CASES, _make, _prompts, _run_product
     from tgis_amd.inference_engine.synthetic import InferenceEngine
     from tgis_amd.models.flash_causal_lm import FlashCausalLM
     from tgis_amd.utils.kv_cache import PagedKVCache
 
     torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
-    name, kw, layers, quantize, dtype, B, L, steps, tol = CFG4
-    cfg, tensors = _make("llama", kw, layers, quantize, dtype, seed=4321)
+    family, (name, kw, layers, quantize, dtype, B, L, steps, tol) = TP_CASES[case]
+    cfg, tensors = _make(family, kw, layers, quantize, dtype, seed=4321)
     prompts = _prompts(B, L, cfg.vocab_size, seed=99)
     tok = FixtureTokenizer(cfg.vocab_size)
     eng = InferenceEngine(tensors, cfg, dtype, quantize, tokenizer=tok)
@@ -229,7 +233,7 @@ def _tp_worker(rank, world, port, ret):
     del tensors
     pages = B * PagedKVCache.pages_for(L + steps + 2) + 8
     lm = FlashCausalLM("fullwidth-tp", None, "synthetic", dtype, quantize, engine=eng, kv_cache_pages=pages)
-    shard_shapes = sorted({(lin.height, lin.width) for lin in lm.model.gptq_linears})
+    shard_shapes = sorted({(lin.height, lin.width) for lin in getattr(lm.model, "gptq_linears", [])})
     batch, got = _run_product(lm, tok, prompts, steps)
     batch.release()
     if rank == 0:
@@ -259,6 +263,28 @@ def test_cfg4_tp8_shard_shapes_match_oracle(gpu_device):
     ref = LlamaRef(cfg, tensors, quantize=quantize, groupsize=128)
     want = ref.generate_greedy(prompts, steps, forced=[g[0] for g in got])
     print(f"\n[{name}] 8 ranks {t1 - t0:.1f} s, oracle {time.time() - t1:.1f} s")
+    _compare(name, got, want, tol, B)
+
+
+def test_cfg5_tp4_shard_shapes_match_oracle(gpu_device):
+    """Starcoder-15B shapes as FOUR ranks on the one GPU (gloo collectives): every rank runs the shipped dense kernels on
+    its shard and the multi-query attention with its 12 q heads on the replicated kv head over a 4096-token context;
+    the gathered logits against the unsharded oracle."""
+    family, (name, kw, layers, quantize, dtype, B, L, steps, tol) = TP_CASES["cfg5"]
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    t0 = time.time()
+    mp.spawn(_tp_worker, args=(4, _free_port(), ret, "cfg5"), nprocs=4, join=True)
+    t1 = time.time()
+    got = ret["got"]
+    assert ret["heads"] == (12, 1), ret["heads"]
+    for r in range(1, 4):
+        assert ret[f"ids{r}"] == [g[0] for g in got], "ranks must stay in lock-step without a broadcast"
+    cfg, tensors = _make(family, kw, layers, quantize, dtype, seed=4321)
+    prompts = _prompts(B, L, cfg.vocab_size, seed=99)
+    ref = SantacoderRef(cfg, tensors)
+    want = ref.generate_greedy(prompts, steps, forced=[g[0] for g in got])
+    print(f"\n[{name}] 4 ranks {t1 - t0:.1f} s, oracle {time.time() - t1:.1f} s")
     _compare(name, got, want, tol, B)
 
 
