@@ -216,7 +216,11 @@ int tgis_layernorm_residual_partial(const float* slabs, int num_slabs, int64_t s
  * half-split (NeoX) rotation using cos/sin tables [max_pos, rot_dim/2] of the model dtype gathered by
  * positions[T] (int32), then writes k and v of token t into KV page slot slots[t]
  * (= page_id*32 + offset).  cos == NULL skips the rotation (learned-position models).
- * k_pool / v_pool: this layer's K and V page pools, [num_pages][Hkv][32*D] each. */
+ * k_pool / v_pool: this layer's K and V page pools, [num_pages][Hkv][32*D] each.  Inside a (page, kv head) block of
+ * 32 tokens x D: K as [token >> 4][D / 8][16 tokens][8], V as [4 column groups][D][8] with token t in column
+ * (i >> 2) * 8 + (t >> 4) * 4 + (i & 3), i = t & 15 (csrc/kv_layout.h, DESIGN.md section 3: the orders in which the
+ * attention kernels' MFMA fragments are whole cache lines).  The pools are opaque to callers; oracle/ops_ref.py's
+ * kv_page_unpack reads them back for tests. */
 int tgis_rope_kv_write(void* qkv, int64_t ld_qkv, const void* cos, const void* sin,
                        const int32_t* positions, const int32_t* slots, void* k_pool, void* v_pool,
                        int64_t T, int H, int Hkv, int D, int rot_dim, int dtype, void* stream);

@@ -51,7 +51,7 @@ CASES = {
     "cfg3-llama7b-gptq-2layer-b4-ctx1024": ("llama", LLAMA_7B, 2, "gptq", torch.float16, 4, 1021, 4, 0.02),
     "cfg5-starcoder-bf16-b32-ctx4096": ("bigcode", STARCODER, 1, None, torch.bfloat16, 32, 4093, 4, 0.12),
 }
-MAX_TIE_ROWS_FRAC = 0.15  # rows per step the oracle itself decides by less than 2 x LOGIT_TOL
+MAX_TIE_ROWS = 2  # rows per step the oracle itself decides by less than 2 x LOGIT_TOL (measured: 0 - 2 per CASE, all steps)
 
 
 def _prompts(B, L, V, seed):
@@ -133,7 +133,7 @@ def _compare(name, got, want, tol, B):
                                         f"prefers it by {gap:.4f} > 2 x {tol}")
                 step_ties += 1
         ties += step_ties
-        assert step_ties <= max(1, int(MAX_TIE_ROWS_FRAC * B)), f"{name} step {i}: {step_ties} of {B} rows flipped"
+        assert step_ties <= MAX_TIE_ROWS, f"{name} step {i}: {step_ties} of {B} rows flipped"
         same = [a == b for a, b in zip(ids, wid)]
         np.testing.assert_allclose(np.array(lps)[same], w["logprobs"].numpy()[same], atol=2 * tol,
                                    err_msg=f"{name} step {i}: logprobs")
