@@ -18,11 +18,11 @@ python - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 def short(n, grid):
-    for k in ("attn_paged_kernel", "gptq_gemm_kernel", "norm_kernel", "dense_gemm_kernel", "argmax"):
+    for k in ("attn_paged_kernel", "gptq_wide_kernel", "gptq_gemm_kernel", "norm_kernel", "dense_gemm_kernel", "argmax"):
         if k in n:
-            if k == "gptq_gemm_kernel":
+            if k in ("gptq_gemm_kernel", "gptq_wide_kernel"):
                 t = n[n.index("<") + 1:n.index(">")].replace(" ", "")
-                return f"gptq_gemm_kernel<{t}> grid {grid}"
+                return f"{k}<{t}> grid {grid}"
             if k == "attn_paged_kernel" or k == "norm_kernel":
                 return f"{k} grid {grid}"
             return k
