@@ -1,8 +1,13 @@
 // Round 4: the PRODUCT's fragment-order int4 GEMM unit (csrc/gptq_wide_body.h, included as is) on arbitrary shapes, with
 // per-wave s_memtime stamps: where does a launch of the 64-row form (MR = 2) spend its time at the Llama-2-70B shapes?
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I text-generation-inference_amd/csrc -o tools/floor/wide_unit tools/floor/wide_unit.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DWIDE_TRACE] -I text-generation-inference_amd/csrc -o tools/floor/wide_unit tools/floor/wide_unit.hip
 //   tools/floor/wide_unit            (random images: timing and timeline only; parity is tests/test_fragments_gpu.py's job)
 #include <hip/hip_runtime.h>
+// Two builds: plain (timing: the unit exactly as the library compiles it) and -DWIDE_TRACE (per-wave stamps).  The stamps must
+// not be in the timed build: a store inside the loop makes hipcc give up its counted vmcnt waits (loads and stores complete
+// out of order with respect to each other), i.e. the traced kernel drains to vmcnt(0) once per iteration — its timeline shows
+// where the time goes, its absolute numbers are a few percent above the library's.
+#ifdef WIDE_TRACE
 static __device__ long long* g_wide_trace = nullptr;   // [blocks][8 waves][8]
 #define WIDE_STAMP(i)                                                                                                    \
     do {                                                                                                                 \
@@ -13,6 +18,7 @@ static __device__ long long* g_wide_trace = nullptr;   // [blocks][8 waves][8]
                 g_wide_trace[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8 + (i)] = t_;  \
         }                                                                                                                \
     } while (0)
+#endif
 #include "gptq_wide_body.h"
 #include <vector>
 #include <algorithm>
@@ -77,6 +83,7 @@ static void run(const char* name, int K, int N, int S, int M) {
     }
     const double mb = ((double)K * N / 2 + (double)im.NT * im.G * 128) / 1e6;
     printf("%-22s M %2d CT %d S %d act %d: blocks %4d  %7.2f us  %5.2f TB/s\n", name, M, CT, S, ACT, cgs * S, best, mb / best);
+#ifdef WIDE_TRACE
     // timeline of one cold launch
     const int nw = cgs * S * 8;
     long long* dtr; CK(hipMalloc(&dtr, (size_t)nw * 64)); CK(hipMemset(dtr, 0, (size_t)nw * 64));
@@ -96,6 +103,7 @@ static void run(const char* name, int K, int N, int S, int M) {
         printf("      %-18s %8lld %8lld %8lld\n", names[k], v[0], v[nw / 2], v[nw - 1]);
     }
     CK(hipFree(dtr));
+#endif
     for (auto p : sets) CK(hipFree(p));
     CK(hipFree(dx)); CK(hipFree(dout)); CK(hipFree(dslabs));
 }
