@@ -60,7 +60,57 @@ struct Args {
     // rstd from the partial sums in the epilogue)
     unsigned* counters; const f16* resid; f16* hout; f16* hfrag; float* ssq;   // ssq [32][NT]
     const f16* normw; const float* ssq_in; int ssq_n; float eps;
+    // EPI 12 (norm-ahead blocks: the add + RMSNorm in front of the GEMM runs on the launch's first 32 workgroups, the GEMM
+    // workgroups request their weights and wait for a counter before they ask for x) and its two-launch baseline
+    const float* nslabs; const f16* nres; f16* nres_out; f16* nxf; unsigned* nflag; unsigned ntarget;
 };
+
+// the add + RMSNorm of norm.hip for one row of 4096 by 512 threads: 4 fp32 slabs + residual -> residual stream, normed row in
+// fragment order.  SC1: write-through stores, drained, then the arrival counter (the row is read by other workgroups of the launch)
+template <bool SC1>
+__device__ __forceinline__ void norm_row_emul(const Args& a, int row, float* sh) {
+    const int c = threadIdx.x;  // chunk of 8 elements
+    const int H = 4096;
+    f32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+        const float* p = a.nslabs + ((int64_t)s2 * 32 + row) * H + c * 8;
+        lo += *reinterpret_cast<const f32x4*>(p);
+        hi += *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    const f16x8 r = *reinterpret_cast<const f16x8*>(a.nres + (int64_t)row * H + c * 8);
+    const f16x8 w = *reinterpret_cast<const f16x8*>(a.normw + c * 8);
+    float v[8], ss = 0.f;
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        v[e] = (float)(f16)(e < 4 ? lo[e] : hi[e - 4]) + (float)r[e];
+        o[e] = (f16)v[e];
+        ss += v[e] * v[e];
+    }
+    __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(a.nres_out, 0, 0x7FFFFFFF, 0x00020000);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(a.nxf, 0, 0x7FFFFFFF, 0x00020000);
+    if (SC1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rr, (uint32_t)(((int64_t)row * H + c * 8) * 2), 0, 16);
+    else *reinterpret_cast<f16x8*>(a.nres_out + (int64_t)row * H + c * 8) = o;
+#pragma unroll
+    for (int of = 32; of > 0; of >>= 1) ss += __shfl_xor(ss, of, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+    for (int k = 0; k < 8; ++k) tot += sh[k];
+    const float rstd = rsqrtf(tot / H + a.eps);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)(v[e] * rstd * (float)w[e]);
+    const int k = c * 8;
+    const int64_t off = ((((k >> 6) << 2) + ((k >> 3) & 3)) * 64 + ((k >> 5) & 1) * 32 + (row & 31)) * 8;
+    if (SC1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rx, (uint32_t)(off * 2), 0, 16);
+    else *reinterpret_cast<f16x8*>(a.nxf + off) = o;
+}
+__global__ __launch_bounds__(512) void norm_emul_kernel(Args a) {
+    __shared__ float sh[16];
+    norm_row_emul<false>(a, blockIdx.x, sh);
+}
 __device__ __forceinline__ int64_t k_off(int tok, int d, int D) {
     return ((int64_t)(((tok >> 4) * (D >> 3) + (d >> 3)) * 16 + (tok & 15)) << 3) + (d & 7);
 }
@@ -73,7 +123,14 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cg = blockIdx.x, split = blockIdx.y;
+    if (EPI == 12 && blockIdx.x < 32) {   // the norm-ahead workgroups
+        norm_row_emul<true>(a, blockIdx.x, reinterpret_cast<float*>(smem));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(a.nflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int cg = EPI == 12 ? blockIdx.x - 32 : blockIdx.x, split = blockIdx.y;
     // this split's steps, then this wave's share of them (contiguous)
     const int sp_len = (a.steps + a.S - 1) / a.S;
     const int sb = split * sp_len, se = min(a.steps, sb + sp_len);
@@ -191,7 +248,17 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
     for (int t = 0; t < CT; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // prologue.  ORD 0: type-major (all x, all scales, all weights); ORD 1: step-major (what step 0 needs first)
-    if (ORD == 0) {
+    if (EPI == 12) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) { load_sz(d, s0 + d); load_w(d, s0 + d); }
+        for (unsigned spins = 0; (int)(__builtin_amdgcn_readfirstlane(__hip_atomic_load(a.nflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - a.ntarget) < 0; ++spins) {
+            __builtin_amdgcn_s_sleep(2);
+            if (spins > (1u << 20)) break;   // never hang the device
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) load_x(d, s0 + d);
+    } else if (ORD == 0) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) if (MODE != 2 && (MODE < 4 || MODE > 5)) load_x(d, s0 + d);
 #pragma unroll
@@ -533,6 +600,14 @@ static float run(const Image& im, const std::vector<uint8_t*>& sets, const f16* 
             CK(hipMalloc(&nw, 32768 * 2)); CK(hipMemset(nw, 0x3c, 32768 * 2));
             CK(hipMalloc(&sq, 32 * 1024 * 4)); CK(hipMalloc(&sqi, 32 * 128 * 4)); CK(hipMemset(sqi, 0x3c, 32 * 128 * 4));
         }
+        static float* nsl = nullptr; static f16 *nr = nullptr, *nro = nullptr, *nx = nullptr; static unsigned* nf = nullptr;
+        if (!nsl) {
+            CK(hipMalloc(&nsl, (size_t)8 * 4 * 32 * 4096 * 4)); CK(hipMemset(nsl, 0, (size_t)8 * 4 * 32 * 4096 * 4));
+            CK(hipMalloc(&nr, 32 * 4096 * 2)); CK(hipMemset(nr, 0x3c, 32 * 4096 * 2));
+            CK(hipMalloc(&nro, 32 * 4096 * 2)); CK(hipMalloc(&nx, 32 * 4096 * 2)); CK(hipMemset(nx, 0, 32 * 4096 * 2));
+            CK(hipMalloc(&nf, 256)); CK(hipMemset(nf, 0, 256));
+        }
+        a.nslabs = nsl; a.nres = nr; a.nres_out = nro; a.nxf = nx; a.nflag = nf; a.ntarget = 0;
         a.counters = cnt; a.resid = res; a.hout = ho; a.hfrag = hf; a.ssq = sq; a.normw = nw; a.ssq_in = sqi; a.ssq_n = 128; a.eps = 1e-5f;
     }
     int spg = im.gs / 64, sh = 0;
@@ -550,6 +625,21 @@ static float run(const Image& im, const std::vector<uint8_t*>& sets, const f16* 
         for (int i = 0; i < iters; ++i) {
             a.prep = sets[i % sets.size()];
             if (EPI >= 3 && getenv("WIDE_COLD")) a.slots = g_slotsets[i % g_slotsets.size()];
+            if (EPI == 12 || EPI == 13) {
+                static unsigned launches = 0;
+                static const float* slab0 = a.nslabs;
+                a.nslabs = slab0 + (size_t)(launches % 8) * 4 * 32 * 4096;   // slabs written "by the kernel before": not in this L2
+                a.xf = a.nxf;
+                if (EPI == 12) {
+                    a.ntarget = 32u * (++launches);
+                    hipLaunchKernelGGL((wide_gemm<CT, WK, DEPTH, MODE, XF, ORD, false, EPI>), dim3(cgs + 32, S), dim3(64 * WK), lds, 0, a);
+                } else {
+                    ++launches;
+                    hipLaunchKernelGGL(norm_emul_kernel, dim3(32), dim3(512), 0, 0, a);
+                    hipLaunchKernelGGL((wide_gemm<CT, WK, DEPTH, MODE, XF, ORD, false, 0>), grid, dim3(64 * WK), lds, 0, a);
+                }
+                continue;
+            }
             hipLaunchKernelGGL((wide_gemm<CT, WK, DEPTH, MODE, XF, ORD, false, EPI>), grid, dim3(64 * WK), lds, 0, a);
         }
         CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
@@ -665,13 +755,9 @@ int main(int argc, char** argv) {
 #define RE(CT, WK, D, S, EPI) (g_ldx = sh.K, run<CT, WK, D, 0, 1, 1, EPI>(im, sets, dx, dout, dslabs, M, S, it, false, hx))
 #define RM(CT, WK, D, S, MODE) (g_ldx = sh.K, run<CT, WK, D, MODE, 1, 1>(im, sets, dx, dout, dslabs, M, S, it, false, hx))
         if (sh.N == 12288) {
-            RX(2, 8, 2, 1); RX(2, 8, 3, 1); RX(4, 8, 2, 1); RX(3, 8, 2, 1);
+            RX(2, 8, 2, 1); RE(2, 8, 2, 1, 13); RE(2, 8, 2, 1, 12);
         } else if (sh.N == 22016) {
-            RX(3, 8, 2, 1); RX(3, 8, 3, 1); RX(4, 8, 2, 1); RX(4, 8, 3, 1);
-        } else if (sh.K == 11008) {
-            RX(2, 8, 2, 4); RX(2, 8, 3, 4); RX(2, 8, 2, 3); RX(3, 8, 2, 6); RX(4, 8, 2, 8);
-        } else {
-            RX(2, 8, 2, 4); RX(2, 8, 3, 4); RX(2, 8, 2, 2); RX(4, 8, 2, 8);
+            RX(3, 8, 2, 1); RE(3, 8, 2, 1, 13); RE(3, 8, 2, 1, 12);
         }
         for (auto p : sets) CK(hipFree(p));
         CK(hipFree(dx)); CK(hipFree(dout)); CK(hipFree(dslabs));
