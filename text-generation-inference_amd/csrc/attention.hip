@@ -694,9 +694,11 @@ unsigned* attn_counters(hipStream_t st) {
     int lru = 0;
     for (int i = 1; i < ATTN_COUNTER_SETS; ++i)
         if (pool.last_use[i] < pool.last_use[lru]) lru = i;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone, ocs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
-    if (!capturing && hipStreamQuery(pool.owner[lru]) == hipSuccess) {
+    // (a query on a stream that is being captured would invalidate its capture: ask that first)
+    const bool owner_capturing = hipStreamIsCapturing(pool.owner[lru], &ocs) != hipSuccess || ocs != hipStreamCaptureStatusNone;
+    if (!capturing && !owner_capturing && hipStreamQuery(pool.owner[lru]) == hipSuccess) {
         pool.owner[lru] = st;
         pool.last_use[lru] = pool.stamp;
         return pool.sets[lru];
