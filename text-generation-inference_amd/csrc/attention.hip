@@ -646,6 +646,7 @@ struct CounterPool {
     unsigned* sets[ATTN_COUNTER_SETS] = {};
     hipStream_t owner[ATTN_COUNTER_SETS] = {};
     uint64_t last_use[ATTN_COUNTER_SETS] = {};  // launch stamp: the least recently used slot is handed to a new stream
+    bool in_graph[ATTN_COUNTER_SETS] = {};      // a captured graph holds this slot's pointer: it never changes hands
     uint64_t stamp = 0;
     int used = 0;
     bool ready = false;
@@ -678,26 +679,31 @@ unsigned* attn_counters(hipStream_t st) {
         pool.ready = true;
     }
     ++pool.stamp;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
     for (int i = 0; i < pool.used; ++i)
         if (pool.owner[i] == st) {
             pool.last_use[i] = pool.stamp;
+            pool.in_graph[i] |= capturing;
             return pool.sets[i];
         }
     if (pool.used < ATTN_COUNTER_SETS) {
         pool.owner[pool.used] = st;
         pool.last_use[pool.used] = pool.stamp;
+        pool.in_graph[pool.used] = capturing;
         return pool.sets[pool.used++];
     }
     // All slots are owned.  A slot whose stream has no launch in flight can change hands (its counters are zero between
     // launches): take the least recently used one if its stream is idle (hipStreamQuery on a destroyed or capturing stream
     // fails — then the slot stays put and this launch uses the separate combine kernel, which is always correct).
-    int lru = 0;
-    for (int i = 1; i < ATTN_COUNTER_SETS; ++i)
-        if (pool.last_use[i] < pool.last_use[lru]) lru = i;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone, ocs = hipStreamCaptureStatusNone;
-    const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    // (a slot whose pointer sits in a captured graph stays where it is: the graph replays on streams this pool never sees)
+    int lru = -1;
+    for (int i = 0; i < ATTN_COUNTER_SETS; ++i)
+        if (!pool.in_graph[i] && (lru < 0 || pool.last_use[i] < pool.last_use[lru])) lru = i;
+    hipStreamCaptureStatus ocs = hipStreamCaptureStatusNone;
     // (a query on a stream that is being captured would invalidate its capture: ask that first)
-    const bool owner_capturing = hipStreamIsCapturing(pool.owner[lru], &ocs) != hipSuccess || ocs != hipStreamCaptureStatusNone;
+    const bool owner_capturing = lru < 0 || hipStreamIsCapturing(pool.owner[lru], &ocs) != hipSuccess ||
+                                 ocs != hipStreamCaptureStatusNone;
     if (!capturing && !owner_capturing && hipStreamQuery(pool.owner[lru]) == hipSuccess) {
         pool.owner[lru] = st;
         pool.last_use[lru] = pool.stamp;
