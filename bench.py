@@ -254,7 +254,11 @@ def bench_causal_lm_cpu(args):
         elapsed = time.perf_counter() - t0
     out = {"metric": f"decode tokens/sec (GPT-2 small fp32 CPU causal_lm, batch {B}) + p50 step latency",
            "value": round(B * K / elapsed, 2), "unit": "tokens/s", "n_gpus": 0, "steps": K, "warmup": W,
-           "ms_per_step": round(elapsed / K * 1e3, 4), "p50_step_ms": round(sorted(step_ms)[len(step_ms) // 2], 4),
+           "ms_per_step": round(elapsed / K * 1e3, 4),
+        # timed blocks of `steps` steps each (fresh batch, same shape); ms_per_step / value are the median block
+        "timed_blocks": len(block_ms_per_step), "ms_per_step_blocks": block_ms_per_step,
+        "ms_per_step_range": [min(block_ms_per_step), max(block_ms_per_step)],
+        "p50_step_ms": round(sorted(step_ms)[len(step_ms) // 2], 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic (seeded random-init GPT-2 small, seeded token ids)",
            "config": {"workload": f"gpt2-small fp32 CPU causal_lm (padded batch), B={B}, L_in={L_in}, prefill + {W} warm-up + "
@@ -286,6 +290,7 @@ def main():
     ap.add_argument("--config", default="llama2-7b-gptq", choices=sorted(list(CONFIGS) + list(CPU_CONFIGS)))
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--ctx", type=int, default=None, help="mean context length over the timed steps")
+    ap.add_argument("--blocks", type=int, default=3, help="timed blocks of --steps steps each; the median block is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -369,24 +374,38 @@ def main():
     from tgis_amd.utils import graph_segments
 
     with lm.context_manager():
-        batch = fresh_batch()
-        for _ in range(W):
-            lm.generate_token(batch)
-        sync()
-        if tp > 1:
-            graph_segments.time_collectives(True)
-        step_ms = []
-        t0 = time.perf_counter()
-        for _ in range(K):
-            ts = time.perf_counter()
-            lm.generate_token(batch)
-            step_ms.append((time.perf_counter() - ts) * 1e3)
-        sync()
-        elapsed = time.perf_counter() - t0
-        if tp > 1:
-            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            elapsed = float(t.item())
+        # Three timed blocks of exactly K steps each, every one on a fresh batch of the same shape (prefill + W warm-up
+        # steps untimed, barrier + synchronize on both sides, max over ranks): the MEDIAN block is the reported
+        # ms_per_step / value, the fastest and slowest are reported as ms_per_step_range.  One pass of 20 steps moved by
+        # as much between boxes (and between runs on one box) as a round of kernel work did.
+        blocks = []
+        batch = None
+        for blk in range(args.blocks):
+            if batch is not None:
+                batch.release()
+                del batch
+            batch = fresh_batch()
+            for _ in range(W):
+                lm.generate_token(batch)
+            sync()
+            if tp > 1 and blk == args.blocks - 1:
+                graph_segments.time_collectives(True)
+            blk_ms = []
+            t0 = time.perf_counter()
+            for _ in range(K):
+                ts = time.perf_counter()
+                lm.generate_token(batch)
+                blk_ms.append((time.perf_counter() - ts) * 1e3)
+            sync()
+            blk_elapsed = time.perf_counter() - t0
+            if tp > 1:
+                t = torch.tensor([blk_elapsed], device=device, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                blk_elapsed = float(t.item())
+            blocks.append((blk_elapsed, blk_ms))
+        order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
+        elapsed, step_ms = blocks[order[len(order) // 2]]
+        block_ms_per_step = [round(b[0] / K * 1e3, 4) for b in blocks]
         coll_us = graph_segments.collective_times_us() if tp > 1 else []
         graph_segments.time_collectives(False)
         ctx_timed_mean = L_in + 1 + W + (K - 1) / 2.0  # keys attended per step, averaged over the timed steps
@@ -477,7 +496,11 @@ def main():
                    if (args.config, B, ctx_mean) == ("llama2-7b-gptq", 32, 1024)
                    else f"decode tokens/sec ({args.config}, batch {B}, ctx {ctx_mean}) + p50 step latency"),
         "value": round(toks_per_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": round(elapsed / K * 1e3, 4), "p50_step_ms": round(sorted(step_ms)[len(step_ms) // 2], 4),
+        "ms_per_step": round(elapsed / K * 1e3, 4),
+        # timed blocks of `steps` steps each (fresh batch, same shape); ms_per_step / value are the median block
+        "timed_blocks": len(block_ms_per_step), "ms_per_step_blocks": block_ms_per_step,
+        "ms_per_step_range": [min(block_ms_per_step), max(block_ms_per_step)],
+        "p50_step_ms": round(sorted(step_ms)[len(step_ms) // 2], 4),
         "graph_ms_per_step": None if graph_ms is None else round(graph_ms, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16",
         "data": "synthetic (seeded weights at the real shapes; KV from a real prefill of seeded token ids)",

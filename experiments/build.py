@@ -1,6 +1,7 @@
-"""Build experiments/lib/libtgis_experiments.so: every product source compiled with -DTGIS_EXPERIMENTS (which re-enables the
-entry points that live behind that macro in csrc/gptq.hip and csrc/attention.hip) plus experiments/csrc/*.hip.
-Not run by __graft_entry__.build(); `python experiments/build.py` when an experiment is wanted."""
+"""Build experiments/lib/libtgis_experiments.so: the product sources plus experiments/csrc/*.hip.  Two experiment units
+(gptq_experiments.hip, attention_experiments.hip) INCLUDE the product's csrc/gptq.hip / csrc/attention.hip whole and add their
+entry points behind them, so those two product files are not compiled a second time.  The product sources carry no
+experiment switches (round 5).  Not run by __graft_entry__.build(); `python experiments/build.py` when an experiment is wanted."""
 import glob
 import os
 import subprocess
@@ -12,10 +13,12 @@ CSRC = os.path.join(ROOT, "text-generation-inference_amd", "csrc")
 
 
 def build() -> str:
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")))
+    wrapped = {"gptq.hip", "attention.hip"}  # compiled through experiments/csrc/{gptq,attention}_experiments.hip
+    srcs = sorted(p for p in glob.glob(os.path.join(CSRC, "*.hip")) if os.path.basename(p) not in wrapped)
+    srcs += sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")))
     objdir = os.path.join(HERE, "lib", "obj")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DTGIS_EXPERIMENTS", "-I", CSRC,
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", CSRC,
              "-I", os.path.join(HERE, "csrc")]
 
     def one(src):

@@ -19,6 +19,7 @@
 #include <utility>
 #include <vector>
 #include "common.h"
+#include "../include/tgis_experiments.h"
 #include "dense_gemm_body.h"
 #include "gptq_gemm_body.h"
 

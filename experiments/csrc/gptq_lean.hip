@@ -4,6 +4,7 @@
 // group-size-128 images without act-order; everything else keeps gptq_gemm_kernel (gptq.hip).
 #include <stdlib.h>
 #include "common.h"
+#include "../include/tgis_experiments.h"
 #include "gptq_ld_body.h"
 
 namespace {

@@ -180,7 +180,11 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
     // (issue and memory return): with k-part = w / TN the k-part of the youngest waves finished 2.5 us (gate_up) after the
     // k-part of the oldest ones, and everybody waited for it; the per-chunk sync of a mixed k-part holds its old waves back
     // instead, which is what lets the young ones catch up.
+#ifdef TGIS_KPART_BY_AGE
+    const int wn = w % TN, wk = w / TN, ltid = wn * 64 + lane;
+#else
     const int wn = TAIL ? w % TN : w / WK, wk = TAIL ? w / TN : w % WK, ltid = wn * 64 + lane;
+#endif
     f16* xs = reinterpret_cast<f16*>(smem) + wk * (2 * XR * RS);  // this k-part's [2][XR][RS]
     const int m0 = mslab * XR;
     const int mrows = min(XR, a.M - m0);
@@ -256,9 +260,11 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             f16x8 v, u;
+#ifndef TAIL_PLAIN_X
             if (TAIL || NORMP) {  // x was written by other workgroups of THIS launch: L1-bypassing loads
                 v = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, rowoff[j] + (uint32_t)kc * 2, 0, 16));
             } else
+#endif
             if (!PERM) {
                 const uint32_t off = rowoff[j] + (uint32_t)kc * 2;
                 v = *(const GLOBAL_AS f16x8*)(xb + off);
@@ -355,12 +361,14 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
         unit_barrier();
     } else {
     stage_load(0);
+#ifndef TGIS_NO_XFIRST_BARRIER
     // Stand-alone kernel: the block-wide barrier that publishes the zeroed counters sits HERE, between the x requests and
     // the weight requests of every wave.  A CU serves its waves' requests in arrival order: without it a later wave's
     // first x chunk queues behind the HBM weight requests of the waves that started before it, and the first chunk was
     // staged only when the whole first ring had arrived (3.1 us after entry for gate_up); with it every x request of the
     // block is in front of every weight request.
     if (!TAIL) unit_barrier();
+#endif
     if (MODE == UNIT_FULL) {
 #pragma unroll
         for (int s = 0; s < RING; ++s)
@@ -370,11 +378,16 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
     }
     // the only block-wide barrier before the reduction publishes the zeroed counters; it does not wait for the loads
     // above, and from here on each k-part group paces itself
+#ifndef TGIS_NO_XFIRST_BARRIER
     if (TAIL) unit_barrier();
+#else
+    unit_barrier();
+#endif
     }
     auto group_sync = [&](int target) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add((lds_int*)sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifndef ABL_NOSYNCWAIT  // ablation: arrive but never wait (wrong results; bounds what a slacker hand-off could gain)
         if (!TAIL) {
             while (__builtin_amdgcn_readfirstlane(*sync_cnt) < target) __builtin_amdgcn_s_sleep(1);
         } else {
@@ -386,6 +399,7 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
                 }
             }
         }
+#endif
         asm volatile("" ::: "memory");
     };
     stage_store(0);
@@ -401,7 +415,9 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
     auto chunk_body = [&](const int chunk, auto sb_tag, auto stage_tag, auto refill_tag) {
         constexpr int SB = decltype(sb_tag)::value;
         constexpr bool STAGE = decltype(stage_tag)::value, REFILL = decltype(refill_tag)::value;
+#ifndef ABL_NOSTAGE
         if (STAGE) stage_load(chunk + 1);
+#endif
         // next chunk's scales: issued before this chunk's weight refills so that the loop-carried copy at the
         // bottom only needs vmcnt(#weight loads) and the weight stream stays in flight across the sync
         uint32_t szn[4];
@@ -422,8 +438,13 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
                 const f16 zc1 = szh[1];
                 const f16 zd1 = (f16)960.f - zc1;  // -(64 + z + 1), exact
                 const f16x2 zc = {zc1, zc1}, zd = {zd1, zd1}, sc = {szh[0], szh[0]};
+#ifdef ABL_NODEQ
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = __builtin_bit_cast(f16x8, u32x4{cur[i], cur[i] ^ EXr, cur[i], cur[i]});
+#else
 #pragma unroll
                 for (int i = 0; i < 4; ++i) b[i] = dequant8(cur[i], zc, zd, sc, EXr, M0r, M1r);
+#endif
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -444,11 +465,17 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+#if defined(ABL_NOMFMA)
+                accs[0][i & 1][0] += (float)b[i][0] + (float)b[i][7];
+#elif defined(ABL_NOLDSREAD)
+                accs[0][i & 1] = mfma32(b[(i + 1) & 3], b[i], accs[0][i & 1]);
+#else
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) {
                     f16x8 av = ld16<f16x8>(xk + mr * (32 * RS) + i * 8);
                     accs[mr][i & (NACC - 1)] = mfma32(av, b[i], accs[mr][i & (NACC - 1)]);
                 }
+#endif
             }
         }
         if (GROUP64 && REFILL) {
@@ -456,7 +483,9 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
             for (int s4 = 0; s4 < 4; ++s4) szr[SB + s4] = szn[s4];
         }
         if (!STAGE) return;
+#ifndef ABL_NOSTAGE
         stage_store((chunk + 1) & 1);
+#endif
         TRACE(3 + 2 * min(chunk, 3));
         group_sync(TN * (chunk + 2));
         TRACE(4 + 2 * min(chunk, 3));

@@ -1,6 +1,7 @@
 /* Entry points of the measured-and-rejected experiments of rounds 2 and 3 (experiments/README.md).  They are NOT part of
- * libtgis_hip.so or of the drop-in boundary: experiments/build.py compiles the product sources with -DTGIS_EXPERIMENTS plus
- * experiments/csrc/*.hip into experiments/lib/libtgis_experiments.so, which exports everything below on top of
+ * libtgis_hip.so or of the drop-in boundary: experiments/build.py compiles the product sources (two of them through the
+ * wrapper units experiments/csrc/{gptq,attention}_experiments.hip) plus the other units of experiments/csrc into
+ * experiments/lib/libtgis_experiments.so, which exports everything below on top of
  * include/tgis_hip.h. */
 #ifndef TGIS_EXPERIMENTS_H
 #define TGIS_EXPERIMENTS_H

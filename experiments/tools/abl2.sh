@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 5): needs the ablation builds of the round-4 tree (experiments/csrc/r04_ablations/, commit 1892754).
 cd "$(dirname "$0")/.."
 code='
 import sys, torch

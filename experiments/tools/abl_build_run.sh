@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE (round 5): the -DABL_* switches live in experiments/csrc/r04_ablations/ now; this script documents how the round-4
+# tree (commit 1892754) was built and timed for profiles/r0[1-3]_*ablations*.log.
 # Build ablation variants of libtgis_hip.so (-DABL_*) here, then time the GEMM shapes on the GPU box:
 #   tools/abl_build_run.sh build      (CPU container)
 #   tools/abl_build_run.sh run        (GPU box)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 5): -DABL_NOSYNCWAIT lives in experiments/csrc/r04_ablations/gptq_gemm_body.h now (round-4 tree, commit 1892754).
 # Upper bound of what a slacker x-chunk hand-off could gain: build with the group wait compiled out (wrong results) and
 # time the cfg3 GEMMs against the product library.
 #   (here)      cd text-generation-inference_amd && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DABL_NOSYNCWAIT -o lib/abl_nosync.so csrc/*.hip

@@ -1,7 +1,8 @@
 """Tall int4 GEMM ablations at M = 4096 (qkv and down shapes): build variants of the library with -DABL_T_NODEQ /
 -DABL_T_NOLDS / -DABL_T_NOSTAGE (wrong results by design) into lib/abl_<variant>.so, then
     TGIS_TALL_MAX_M=100000 TGIS_TALL_TW=2 TGIS_HIP_LIB=$PWD/text-generation-inference_amd/lib/abl_T_NODEQ.so python tools/abl_tall.py
-GPU box only."""
+GPU box only.
+NOTE (round 5): the -DABL_T_* switches live in experiments/csrc/r04_ablations/gptq.hip.txt (round-4 tree, commit 1892754)."""
 import os, sys, torch
 sys.path.insert(0, "tools"); sys.path.insert(0, "text-generation-inference_amd")
 import microbench as mb

@@ -1,14 +1,14 @@
 """Decode attention with the rotary embedding + cache write in its prologue (tgis_attn_decode_rope) against the two
 launches it replaces (tgis_rope_kv_write_partial + tgis_attn_paged), GPU time per layer-step from a captured graph.
-    python tools/attn_fused_bench.py B H Hkv D ctx [S]"""
+    python experiments/build.py && python experiments/tools/attn_fused_bench.py B H Hkv D ctx [S]"""
 import sys
 
 import torch
 
+sys.path.insert(0, "experiments")
+import native_experiments as nat  # noqa: E402  (binds libtgis_experiments.so; must come before anything loads the product library)
 sys.path.insert(0, "tools")
-sys.path.insert(0, "text-generation-inference_amd")
 import microbench as mb  # noqa: E402
-from tgis_amd import native as nat  # noqa: E402
 
 dev = mb.dev
 B, H, Hkv, D, ctx = (int(v) for v in sys.argv[1:6]) if len(sys.argv) >= 6 else (32, 32, 32, 128, 1024)

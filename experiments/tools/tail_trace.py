@@ -1,7 +1,8 @@
 """Phase timeline of the persistent decode tail (csrc/decode_tail.hip): per workgroup s_memrealtime stamps at the
 phase edges -> median / max duration of every phase and barrier.  GPU box only.
-    python tools/tail_trace.py            cfg3 shapes (Llama-2-7B, int4 GPTQ, fp16)
-    python tools/tail_trace.py dense      cfg2 shapes (TinyLlama-1.1B, dense bf16);  M=<rows> in the environment"""
+    python experiments/build.py first;
+    python experiments/tools/tail_trace.py            cfg3 shapes (Llama-2-7B, int4 GPTQ, fp16)
+    python experiments/tools/tail_trace.py dense      cfg2 shapes (TinyLlama-1.1B, dense bf16);  M=<rows> in the environment"""
 import ctypes
 import os
 import sys
@@ -9,9 +10,9 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "text-generation-inference_amd"))
-from tgis_amd import native as nat  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "experiments"))
+import native_experiments as nat  # noqa: E402  (tgis_amd.native bound to libtgis_experiments.so + the experimental calls)
 
 dev = torch.device("cuda:0")
 DENSE = len(sys.argv) > 1 and sys.argv[1] == "dense"

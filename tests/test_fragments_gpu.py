@@ -83,6 +83,29 @@ def test_fragment_gemm_matches_the_oracle_and_the_row_major_launch(nat, gpu_devi
     assert float(dd.max()) <= 2.0 ** -9 * float(want.abs().max()) + 1e-3
 
 
+@pytest.mark.parametrize("order", [(16, 48), (48, 16)])
+def test_deferred_reduce_plan_follows_the_row_class(nat, gpu_device, order):
+    """One GptqWeight serving a <= 32-row and then a 33 - 64-row decode batch (continuous batching: concatenate / prune move a
+    batch across 32 rows): the split plan of the fragment-order kernel differs between the two row classes on long k ranges
+    (plan_wide: 70B down_proj S 2 vs 4), so the cached (S, ld) of one class must never describe the slabs of the other."""
+    K, N, gs = 28672, 1024, 128
+    (qw, qz, sc, gi), w = _weight(nat, gpu_device, K, N, gs, seed=77)
+    seen = []
+    for M in order:
+        g = torch.Generator().manual_seed(M)
+        x = (torch.randn(M, K, generator=g) * 0.25).half()
+        want = ops_ref.gptq_linear(x, qw, qz, sc, gi, gs, None)
+        xf = nat.FragAct.from_rows(x.to(gpu_device))
+        for _ in range(2):  # first call of a row class asks the library, the second one uses the cached plan
+            p = nat.gptq_gemm_partial(xf, w)
+            rb = (M + 31) // 32
+            got = p.slabs[:rb * p.S * 32 * p.ld].view(rb, p.S, 32, p.ld).sum(1).reshape(rb * 32, p.ld)[:M, :N]
+            err = (got.cpu() - want).abs()
+            assert bool((err <= 2e-3 * float(want.abs().mean()) + 1e-4 + 2e-3 * want.abs()).all()), (M, p.S, float(err.max()))
+        seen.append(p.S)
+    assert len(w.partial_plan) == 2, "one cached plan per row class"
+
+
 @pytest.mark.parametrize("M,K,I", [(32, 4096, 11008), (9, 1024, 1408), (32, 2048, 5632), (64, 4096, 11008), (45, 8192, 3584)])
 def test_fragment_gemm_silu_epilogue_and_fragment_output(nat, gpu_device, M, K, I):
     """gate_up on the interleaved image with a fragment-order operand: row-major and fragment-order outputs hold the same

@@ -4,9 +4,6 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/tgis_hip.h"
-#ifdef TGIS_EXPERIMENTS  // the experiments library (experiments/build.py) exports its own header on top
-#include "../../experiments/include/tgis_experiments.h"
-#endif
 
 typedef _Float16 f16;
 typedef __bf16 bf16;

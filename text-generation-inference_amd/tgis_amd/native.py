@@ -307,7 +307,7 @@ class GptqWeight:
 def gptq_gemm(x, w: GptqWeight, ws: Workspace, bias=None, act: int = 0, out=None, out_frag: bool = False):
     """act 0: out[M,N] = x @ dequant(W) (+bias); act 1: x is [M,2K], silu(x[:, :K]) * x[:, K:] is the operand;
     act 2 (weight prepared with gate_up=True): out[M,N/2] = silu(gate) * up.
-    x may be a FragAct (decode, M <= 32); with act 2 the result may then leave as a FragAct too (out_frag)."""
+    x may be a FragAct (decode, M <= 64); with act 2 the result may then leave as a FragAct too (out_frag)."""
     assert act != 2 or w.flags & 1, "act=2 needs a weight prepared with gate_up=True"
     if isinstance(x, FragAct):
         assert x.K == w.K and act in (0, 2) and w.perm is None
@@ -361,9 +361,10 @@ def gptq_gemm_partial(x: torch.Tensor, w: GptqWeight, bias=None, act: int = 0) -
     """Launch the GEMM but leave the split-K reduce (and bias) to the consumer.  Slabs are stored in 32-row units:
     [ceil(M/32)][S][32][ld]."""
     lib = load_library()
-    if isinstance(x, FragAct):  # decode, <= 32 rows: the fragment-order kernel and ITS split plan
+    if isinstance(x, FragAct):  # decode, <= 64 rows: the fragment-order kernel and ITS split plan
         assert x.K == w.K and act == 0 and w.perm is None
-        M, key, xp, ldx = x.M, "frag", _ptr(x.buf), LD_FRAGMENTS
+        # the split plan of the fragment-order kernel depends on the row class (plan_wide: <= 32 rows / 33 - 64 rows)
+        M, key, xp, ldx = x.M, ("frag", x.M > 32), _ptr(x.buf), LD_FRAGMENTS
     else:
         assert x.dtype == torch.float16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] <= PARTIAL_MAX_M
         M = x.shape[0]

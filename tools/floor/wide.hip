@@ -524,6 +524,229 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 5: the same unit re-cut to answer VERDICT r04 item 1 (ramp and drain of a launch):
+//   DW / DX  k64-steps of weights (+ scales) / of activation in flight per wave, separately: weights come from HBM (long
+//            latency, 1 KiB per tile-step and 4 VGPRs), the activation from L2 (short latency, 4 KiB per step, 16 VGPRs);
+//   ORD 2    prologue requests every weight step before any activation;
+//   PRIO     s_setprio 1 for the younger half of the block's waves (a CU serves its older waves first);
+//   PRE      every cache line of the kernel arguments is requested at entry (one scalar round trip instead of three);
+//   WK 4     four-wave blocks: 32 KiB of LDS at CT 2, <= 128 VGPRs -> up to four blocks per CU, more blocks than CUs.
+//   KB       k64-steps that every wave of the older half of the block takes over from its partner in the younger half: the
+//            younger half starts its stream ~2.4 k ticks later (its prologue requests queue behind the older half's in the
+//            CU's 64 B/clk address path) and everybody waits for it at the k-part exchange (profiles/r05_wide_timeline.log);
+//   PB       a block barrier between the prologue's step-0 requests and its later steps (every wave's first step ahead of
+//            anybody's second);
+//   EPI      0 plain; 20 SiLU * up on the interleaved image, row-major; 21 the same in fragment order (2-byte stores, the
+//            product's OUTF); 22 fragment order through LDS: 16-byte stores.
+template <int CT, int WK, int DW, int DX, int ORD, int PRIO, int PRE, bool TR, int KB = 0, int PB = 0, int EPI = 0>
+__global__ __launch_bounds__(64 * WK) void wide2_gemm(Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    static_assert(DW % DX == 0, "the activation ring divides the weight ring");
+    if (PRE) {
+        const int p0 = a.rD; const void* p1 = a.ssq; const void* p2 = a.nflag; const void* p3 = a.slabs;
+        asm volatile("" :: "s"(p0), "s"(p1), "s"(p2), "s"(p3));
+    }
+    const int lane = threadIdx.x & 63;
+    const int wk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (PRIO == 1) { if (wk >= WK / 2) __builtin_amdgcn_s_setprio(1); }
+    if (PRIO == 2) { if (wk < WK / 2) __builtin_amdgcn_s_setprio(1); }
+    const int cg = blockIdx.x, split = blockIdx.y;
+    const int sp_len = (a.steps + a.S - 1) / a.S;
+    const int sb = split * sp_len, se = min(a.steps, sb + sp_len);
+    const int len = max(se - sb, 0);
+    // boundaries f(w) = len w / WK + kb (min(w, WK/2) - max(w - WK/2, 0)): the older half gets kb steps more per wave
+    const int kb = min(KB, max(len / WK - 1, 0));
+    auto bound = [&](int w) { return sb + (len * w) / WK + kb * (min(w, WK / 2) - max(w - WK / 2, 0)); };
+    const int s0 = bound(wk), s1 = bound(wk + 1);
+    const int mrows = min(32, a.M);
+    long long stamp[8];
+    STAMP(0);
+    if (TR) stamp[7] = __builtin_amdgcn_s_memrealtime();
+
+    const char* wt[CT];
+    const char* st[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int nt = min(cg * CT + t, a.NT - 1);
+        wt[t] = reinterpret_cast<const char*>(a.prep) + (int64_t)nt * a.KS * 1024;
+        st[t] = reinterpret_cast<const char*>(a.prep + a.offB) + (int64_t)nt * a.G * 128;
+    }
+    const uint32_t woff = lane * 16, szoff = (lane & 31) * 4;
+    const int sclamp = max(s1 - 1, s0);
+
+    u32x4 wq[DW][CT];
+    uint32_t sz[DW][CT];
+    f16x8 xa[DX][4];
+    auto load_x = [&](int d, int step) {
+        const char* p = reinterpret_cast<const char*>(a.xf) + (int64_t)min(step, sclamp) * 4096;
+        PIN_SGPR(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xa[d][i] = *(const GLOBAL_AS f16x8*)(p + woff + i * 1024);
+    };
+    auto load_w = [&](int d, int step) {
+        const int sc = min(step, sclamp);
+        const int g = min(sc >> a.spg_shift, a.G - 1);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const char* p = st[t] + (int64_t)g * 128;
+            PIN_SGPR(p);
+            sz[d][t] = *(const GLOBAL_AS uint32_t*)(p + szoff);
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const char* p = wt[t] + (int64_t)sc * 1024;
+            PIN_SGPR(p);
+            wq[d][t] = __builtin_nontemporal_load((const GLOBAL_AS u32x4*)(p + woff));
+        }
+    };
+    uint32_t EXr = 0x64006400u, M0r = 0x000F000Fu, M1r = 0x00F000F0u;
+    asm volatile("" : "+v"(EXr));
+    asm volatile("" : "+s"(M0r), "+s"(M1r));
+    f32x16 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    if (ORD == 2) {
+#pragma unroll
+        for (int d = 0; d < DW; ++d) load_w(d, s0 + d);
+#pragma unroll
+        for (int d = 0; d < DX; ++d) load_x(d, s0 + d);
+    } else {
+#pragma unroll
+        for (int d = 0; d < DW; ++d) {
+            load_w(d, s0 + d);
+            if (d < DX) load_x(d, s0 + d);
+            if (PB && d == 0) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+        }
+    }
+    auto consume = [&](int d) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const f16x2 szh = __builtin_bit_cast(f16x2, sz[d][t]);
+            const f16 zc1 = szh[1];
+            const f16 zd1 = (f16)960.f - zc1;
+            const f16x2 zc = {zc1, zc1}, zd = {zd1, zd1}, sc = {szh[0], szh[0]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f16x8 b = dequant8(wq[d][t][i], zc, zd, sc, EXr, M0r, M1r);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[d % DX][i], b, acc[t], 0, 0, 0);
+            }
+        }
+    };
+    STAMP(1);
+    int s = s0;
+    for (; s + DW < s1; s += DW) {
+#pragma unroll
+        for (int d = 0; d < DW; ++d) {
+            consume(d);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(d, s + d + DW);
+            load_x(d % DX, s + d + DX);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    STAMP(2);
+    // the last group: the steps that exist; the activation ring is shorter than the weight ring, so it is still refilled
+#pragma unroll
+    for (int d = 0; d < DW; ++d) {
+        if (s + d < s1) consume(d);
+        if (d + DX < DW) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_x(d % DX, s + d + DX);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (d == 0) STAMP(3);
+    }
+    STAMP(4);
+    constexpr int NR = 16 / WK;
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        float* dst = red + ((wk * CT + t) << 10) + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r << 6] = acc[t][r];
+    }
+    __syncthreads();
+    STAMP(5);
+    float fin[CT][NR];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+#pragma unroll
+        for (int k2 = 0; k2 < WK; ++k2) {
+            const float* src = red + ((k2 * CT + t) << 10) + ((wk * NR) << 6) + lane;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) fin[t][j] = k2 == 0 ? src[j << 6] : fin[t][j] + src[j << 6];
+        }
+    }
+    const int c = lane & 31;
+    if (EPI >= 20) {
+        // SiLU * up on the interleaved image: lanes c < 16 hold gate column j2, lanes c + 16 the matching up column
+        const int half = a.N >> 1;
+        f16* stg = reinterpret_cast<f16*>(smem + (size_t)WK * CT * 4096);   // [32 rows][CT * 16] halves (EPI 22)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int nt = cg * CT + t;
+            const int j2 = nt * 16 + (c & 15);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int r = wk * NR + j;
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float mine = (float)(f16)fin[t][j];
+                const float other = __shfl_xor(mine, 16, 64);
+                const float sl = mine / (1.f + __expf(-mine));
+                const f16 o = (f16)((float)(f16)sl * other);
+                if (EPI == 22) {
+                    if (c < 16) stg[m * (CT * 16) + t * 16 + c] = o;
+                } else if (c < 16 && nt < a.NT && j2 < half && m < mrows) {
+                    if (EPI == 21) {
+                        const int k = j2;
+                        a.out[((((k >> 6) << 2) + ((k >> 3) & 3)) * 64 + ((k >> 5) & 1) * 32 + (m & 31)) * 8 + (k & 7)] = o;
+                    } else {
+                        a.out[(int64_t)m * half + j2] = o;
+                    }
+                }
+            }
+        }
+        if (EPI == 22) {
+            __syncthreads();
+            constexpr int CH = CT * 2;   // 16-byte chunks per row
+            for (int id = threadIdx.x; id < 32 * CH; id += 64 * WK) {
+                const int m = id / CH, ch = id - m * CH;
+                const int k = cg * CT * 16 + ch * 8;
+                if (k < half && m < mrows) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(stg + m * (CT * 16) + ch * 8);
+                    *reinterpret_cast<u32x4*>(a.out + ((((k >> 6) << 2) + ((k >> 3) & 3)) * 64 + ((k >> 5) & 1) * 32 + m) * 8) = v;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int nt = cg * CT + t;
+        if (nt >= a.NT) break;
+        const int n = nt * 32 + c;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int r = wk * NR + j;
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (a.S == 1) {
+                if (m < mrows && n < a.N) a.out[(int64_t)m * a.ldo + n] = (f16)fin[t][j];
+            } else {
+                a.slabs[((int64_t)split * 32 + m) * (a.NT * 32) + n] = fin[t][j];
+            }
+        }
+    }
+    }
+    STAMP(6);
+    if (TR && lane == 0) {
+        long long* tp = a.trace + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WK + wk) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tp[i] = stamp[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 struct Image {
     int K, N, NT, KS, G, gs;
@@ -702,6 +925,104 @@ static float run(const Image& im, const std::vector<uint8_t*>& sets, const f16* 
     return best;
 }
 
+
+// ---- round 5 runner: wide2_gemm, timed as back-to-back launches over rotating weight sets; WIDE_TRACE=1 adds the per-wave
+// timeline, overall and by wave index (is the arrival skew systematic by wave age?)
+template <int CT, int WK, int DW, int DX, int ORD = 1, int PRIO = 0, int PRE = 0, int KB = 0, int PB = 0, int EPI = 0>
+static float run2(const Image& im, const std::vector<uint8_t*>& sets, const f16* dx, f16* dout, float* dslabs, int M, int S,
+                  int iters, const std::vector<f16>& hx) {
+    Args a;
+    memset(&a, 0, sizeof(a));
+    a.x = dx; a.ldx = im.K; a.xf = g_xf; a.out = dout; a.ldo = im.N; a.slabs = dslabs;
+    a.M = M; a.K = im.K; a.N = im.N; a.NT = im.NT; a.KS = im.KS; a.G = im.G;
+    a.offB = im.offB; a.S = S; a.steps = im.K / 64; a.trace = nullptr;
+    int spg = im.gs / 64, sh = 0;
+    while ((1 << sh) < spg) ++sh;
+    a.spg_shift = sh;
+    const int cgs = (im.NT + CT - 1) / CT;
+    const size_t lds = (size_t)WK * CT * 4096 + (EPI == 22 ? 32 * CT * 16 * 2 : 0);
+    auto kern = wide2_gemm<CT, WK, DW, DX, ORD, PRIO, PRE, false, KB, PB, EPI>;
+    auto kern_tr = wide2_gemm<CT, WK, DW, DX, ORD, PRIO, PRE, true, KB, PB, EPI>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)kern_tr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 64 * WK, lds));
+    dim3 grid(cgs, S);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) {
+            a.prep = sets[i % sets.size()];
+            hipLaunchKernelGGL(kern, grid, dim3(64 * WK), lds, 0, a);
+        }
+        CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms * 1000.f / iters);
+    }
+    // check
+    double maxerr = 0;
+    if (EPI == 0) {
+        a.prep = sets[0];
+        CK(hipMemset(dout, 0, (size_t)32 * im.N * 2));
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WK), lds, 0, a);
+        CK(hipDeviceSynchronize());
+        std::vector<f16> ho((size_t)32 * im.N);
+        std::vector<float> hs;
+        if (S == 1) CK(hipMemcpy(ho.data(), dout, ho.size() * 2, hipMemcpyDeviceToHost));
+        else { hs.resize((size_t)S * 32 * im.NT * 32); CK(hipMemcpy(hs.data(), dslabs, hs.size() * 4, hipMemcpyDeviceToHost)); }
+        for (int t = 0; t < 32; ++t) {
+            const int m = rnd() % M, n = t < 4 ? (t & 1 ? im.N - 1 - (t >> 1) : (t >> 1)) : rnd() % im.N;
+            double got;
+            if (S == 1) got = (float)ho[(size_t)m * im.N + n];
+            else { got = 0; for (int s2 = 0; s2 < S; ++s2) got += hs[((size_t)s2 * 32 + m) * (im.NT * 32) + n]; }
+            const double want = ref_dot(im, hx, im.K, m, n);
+            maxerr = std::max(maxerr, fabs(got - want) / (1.0 + fabs(want)));
+        }
+    }
+    const int blocks = cgs * S;
+    const double mb = (double)(im.offB * 1.0 * (im.K / 64) / im.KS + (double)im.NT * im.G * 128) / 1e6;
+    printf("  CT %d WK %2d DW %d DX %d S %2d ord %d prio %d pre %d kb %d pb %d epi %2d: blocks %4d (%d/CU fit)  %6.2f us  %5.2f TB/s  relerr %.1e%s\n", CT, WK, DW, DX, S, ORD,
+           PRIO, PRE, KB, PB, EPI, blocks, occ, best, mb / best, maxerr, maxerr > 3e-3 ? "  <-- WRONG" : "");
+    if (getenv("WIDE_TRACE")) {
+        const int nw = cgs * S * WK;
+        long long* dtr; CK(hipMalloc(&dtr, (size_t)nw * 8 * 8)); CK(hipMemset(dtr, 0, (size_t)nw * 8 * 8));
+        a.trace = dtr;
+        for (int i = 0; i < 4; ++i) {
+            a.prep = sets[(i + 3) % sets.size()];
+            hipLaunchKernelGGL(kern_tr, grid, dim3(64 * WK), lds, 0, a);
+        }
+        CK(hipDeviceSynchronize());
+        std::vector<long long> tr((size_t)nw * 8);
+        CK(hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost));
+        long long rt0 = tr[7];
+        for (int i = 0; i < nw; ++i) rt0 = std::min(rt0, tr[(size_t)i * 8 + 7]);
+        {
+            std::vector<long long> v(nw);
+            for (int i = 0; i < nw; ++i) v[i] = (tr[(size_t)i * 8 + 7] - rt0) * 10;
+            std::sort(v.begin(), v.end());
+            printf("    wave entry after the first wave's entry (ns): median %lld  p90 %lld  max %lld\n", v[nw / 2], v[nw * 9 / 10], v[nw - 1]);
+        }
+        const char* names[7] = {"entry", "prologue issued", "loop done", "first of last group", "last group done", "after barrier", "stored"};
+        printf("    ticks from the wave's own entry, min / median / max over %d waves; then medians by wave index 0..%d\n", nw, WK - 1);
+        for (int k = 1; k < 7; ++k) {
+            std::vector<long long> v(nw);
+            for (int i = 0; i < nw; ++i) v[i] = tr[(size_t)i * 8 + k] - tr[(size_t)i * 8];
+            std::sort(v.begin(), v.end());
+            printf("      %-20s %6lld %6lld %6lld |", names[k], v[0], v[nw / 2], v[nw - 1]);
+            for (int w = 0; w < WK; ++w) {
+                std::vector<long long> u;
+                for (int i = w; i < nw; i += WK) u.push_back(tr[(size_t)i * 8 + k] - tr[(size_t)i * 8]);
+                std::sort(u.begin(), u.end());
+                printf(" %6lld", u[u.size() / 2]);
+            }
+            printf("\n");
+        }
+        CK(hipFree(dtr));
+    }
+    return best;
+}
+
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 32;
     {   // rope operands at the cfg3 shape: 32 rows, 32 + 32 + 32 heads of 128, one page of 32 tokens per (page, head)
@@ -754,7 +1075,59 @@ int main(int argc, char** argv) {
 #define RX0(CT, WK, D, S) (g_ldx = sh.K, run<CT, WK, D, 0, 1, 0>(im, sets, dx, dout, dslabs, M, S, it, true, hx))
 #define RE(CT, WK, D, S, EPI) (g_ldx = sh.K, run<CT, WK, D, 0, 1, 1, EPI>(im, sets, dx, dout, dslabs, M, S, it, false, hx))
 #define RM(CT, WK, D, S, MODE) (g_ldx = sh.K, run<CT, WK, D, MODE, 1, 1>(im, sets, dx, dout, dslabs, M, S, it, false, hx))
-        if (sh.N == 12288) {
+#define R2(CT, WK, DW, DX, S, ...) run2<CT, WK, DW, DX, ##__VA_ARGS__>(im, sets, dx, dout, dslabs, M, S, it, hx)
+        const char* suite = getenv("WIDE_SUITE") ? getenv("WIDE_SUITE") : "r04";
+        if (!strcmp(suite, "r05a")) {
+            // the shipped plan of each shape first (DW = DX = 2, ord 1), then one change at a time
+            if (sh.N == 12288) {
+                R2(2, 8, 2, 2, 1); R2(2, 8, 2, 2, 1, 1, 0, 1); R2(2, 8, 2, 2, 1, 2); R2(2, 8, 2, 2, 1, 1, 1); R2(2, 8, 2, 2, 1, 1, 2);
+                R2(2, 8, 4, 2, 1); R2(2, 8, 4, 2, 1, 2); R2(2, 8, 3, 1, 1); R2(2, 8, 4, 1, 1); R2(2, 8, 2, 1, 1);
+                R2(2, 4, 2, 2, 1); R2(2, 4, 4, 2, 1); R2(1, 4, 4, 2, 1); R2(1, 4, 2, 2, 1); R2(1, 8, 4, 2, 1); R2(3, 8, 4, 2, 1); R2(3, 4, 4, 2, 1);
+            } else if (sh.N == 22016) {
+                R2(3, 8, 2, 2, 1); R2(3, 8, 2, 2, 1, 1, 0, 1); R2(3, 8, 2, 2, 1, 2); R2(3, 8, 2, 2, 1, 1, 1); R2(3, 8, 2, 2, 1, 1, 2);
+                R2(3, 8, 4, 2, 1); R2(3, 8, 4, 2, 1, 2); R2(3, 8, 3, 1, 1); R2(3, 8, 4, 1, 1);
+                R2(2, 4, 2, 2, 1); R2(2, 4, 4, 2, 1); R2(3, 4, 4, 2, 1); R2(2, 8, 4, 2, 1); R2(1, 4, 4, 2, 1); R2(4, 8, 4, 2, 1);
+            } else if (sh.K == 4096) {   // o
+                R2(2, 8, 2, 2, 4); R2(2, 8, 2, 2, 4, 1, 0, 1); R2(2, 8, 2, 2, 4, 2); R2(2, 8, 2, 2, 4, 1, 1);
+                R2(2, 8, 4, 2, 4); R2(2, 8, 2, 1, 4); R2(2, 8, 2, 2, 2); R2(2, 8, 4, 2, 2);
+                R2(2, 4, 2, 2, 4); R2(2, 4, 4, 2, 4); R2(2, 4, 2, 2, 8); R2(2, 4, 4, 2, 8); R2(1, 4, 2, 2, 4); R2(1, 4, 4, 2, 4); R2(1, 4, 4, 2, 2); R2(1, 8, 4, 2, 2);
+            } else {   // down
+                R2(2, 8, 2, 2, 4); R2(2, 8, 2, 2, 4, 1, 0, 1); R2(2, 8, 2, 2, 4, 2); R2(2, 8, 2, 2, 4, 1, 1);
+                R2(2, 8, 4, 2, 4); R2(2, 8, 4, 2, 4, 2); R2(2, 8, 2, 1, 4); R2(2, 8, 4, 2, 2); R2(2, 8, 4, 2, 3);
+                R2(2, 4, 2, 2, 4); R2(2, 4, 4, 2, 4); R2(2, 4, 4, 2, 8); R2(2, 4, 4, 2, 6); R2(1, 4, 4, 2, 4); R2(1, 4, 4, 2, 2); R2(1, 8, 4, 2, 2);
+            }
+        } else if (!strcmp(suite, "r05b")) {
+            // the weighted k split (kb), with / without the argument prefetch, the priority of the younger half, the prologue barrier
+            if (sh.N == 12288) {
+                R2(2, 8, 2, 2, 1); R2(2, 8, 2, 2, 1, 1, 0, 0, 1); R2(2, 8, 2, 2, 1, 1, 0, 0, 2); R2(2, 8, 2, 2, 1, 1, 0, 0, 3);
+                R2(2, 8, 2, 2, 1, 1, 0, 1, 1); R2(2, 8, 2, 2, 1, 1, 0, 1, 2); R2(2, 8, 2, 2, 1, 1, 1, 1, 1); R2(2, 8, 2, 2, 1, 1, 1, 1, 2);
+                R2(2, 8, 2, 2, 1, 1, 0, 1, 0, 1); R2(2, 8, 2, 2, 1, 1, 0, 1, 1, 1); R2(2, 8, 2, 2, 1, 1, 0, 1, 2, 1);
+            } else if (sh.N == 22016) {
+                R2(3, 8, 2, 2, 1); R2(3, 8, 2, 2, 1, 1, 0, 0, 1); R2(3, 8, 2, 2, 1, 1, 0, 0, 2); R2(3, 8, 2, 2, 1, 1, 0, 0, 3);
+                R2(3, 8, 2, 2, 1, 1, 0, 1, 1); R2(3, 8, 2, 2, 1, 1, 0, 1, 2); R2(3, 8, 2, 2, 1, 1, 1, 1, 1); R2(3, 8, 2, 2, 1, 1, 1, 1, 2);
+                R2(3, 8, 2, 2, 1, 1, 0, 1, 0, 1); R2(3, 8, 2, 2, 1, 1, 0, 1, 1, 1); R2(3, 8, 2, 2, 1, 1, 0, 1, 2, 1);
+                // SiLU * up epilogues on the best split so far and on the plain one
+                R2(3, 8, 2, 2, 1, 1, 0, 1, 0, 0, 20); R2(3, 8, 2, 2, 1, 1, 0, 1, 0, 0, 21); R2(3, 8, 2, 2, 1, 1, 0, 1, 0, 0, 22);
+                R2(3, 8, 2, 2, 1, 1, 0, 1, 1, 0, 21); R2(3, 8, 2, 2, 1, 1, 0, 1, 1, 0, 22);
+            } else if (sh.K == 4096) {   // o
+                R2(2, 8, 2, 2, 4); R2(2, 8, 2, 2, 4, 1, 0, 0, 1); R2(2, 8, 2, 2, 4, 1, 0, 1, 1); R2(2, 8, 2, 2, 4, 1, 1, 1, 1);
+                R2(2, 8, 2, 2, 4, 1, 0, 1, 0, 1); R2(2, 8, 2, 2, 4, 1, 0, 1, 1, 1); R2(2, 8, 2, 2, 2, 1, 0, 1, 1); R2(2, 8, 2, 2, 2, 1, 0, 1, 2);
+                R2(2, 8, 2, 2, 3, 1, 0, 1, 1);
+            } else {   // down
+                R2(2, 8, 2, 2, 4); R2(2, 8, 2, 2, 4, 1, 0, 0, 1); R2(2, 8, 2, 2, 4, 1, 0, 0, 2); R2(2, 8, 2, 2, 4, 1, 0, 1, 1); R2(2, 8, 2, 2, 4, 1, 0, 1, 2);
+                R2(2, 8, 2, 2, 4, 1, 1, 1, 1); R2(2, 8, 2, 2, 4, 1, 0, 1, 0, 1); R2(2, 8, 2, 2, 4, 1, 0, 1, 1, 1); R2(2, 8, 2, 2, 3, 1, 0, 1, 1); R2(2, 8, 2, 2, 3, 1, 0, 1, 2);
+                R2(2, 8, 2, 2, 2, 1, 0, 1, 2); R2(2, 8, 2, 2, 2, 1, 0, 1, 3);
+            }
+        } else if (!strcmp(suite, "r05t")) {   // run with WIDE_TRACE=1: timelines of the shipped plans and of the deeper weight ring
+            if (getenv("WIDE_T2")) {   // second trace set: the weighted split
+                if (sh.N == 12288) { R2(2, 8, 2, 2, 1, 1, 0, 1, 1); R2(2, 8, 2, 2, 1, 1, 0, 1, 2); }
+                else if (sh.N == 22016) { R2(3, 8, 2, 2, 1, 1, 0, 1, 1); R2(3, 8, 2, 2, 1, 1, 0, 1, 2); R2(3, 8, 2, 2, 1, 1, 0, 1, 1, 0, 22); }
+                else { R2(2, 8, 2, 2, 4, 1, 0, 1, 1); }
+            }
+            else if (sh.N == 12288) { R2(2, 8, 2, 2, 1); R2(2, 8, 4, 2, 1); R2(2, 4, 4, 2, 1); }
+            else if (sh.N == 22016) { R2(3, 8, 2, 2, 1); R2(3, 8, 4, 2, 1); R2(2, 4, 4, 2, 1); }
+            else { R2(2, 8, 2, 2, 4); R2(2, 8, 4, 2, 4); R2(2, 4, 4, 2, 4); }
+        } else if (sh.N == 12288) {
             RX(2, 8, 2, 1); RE(2, 8, 2, 1, 13); RE(2, 8, 2, 1, 12);
         } else if (sh.N == 22016) {
             RX(3, 8, 2, 1); RE(3, 8, 2, 1, 13); RE(3, 8, 2, 1, 12);
