@@ -413,3 +413,17 @@ def test_kv_layout_time_axis_operations():
     assert back.shape == (len(keep) * H, D, n)
     assert torch.equal(back.view(len(keep), H, D, n).permute(0, 1, 3, 2), k[keep][:, :, T - n:, :])
     assert merged.by_row(m, B) is m and merged.slots(m) == [m] and merged.pack([m]) is m
+
+
+def test_reference_layout_flags_are_assignable():
+    """The reference's batch classes SET keys_head_dim_last / merged_kv_cache (causal_lm.py:742-756); here they are views of
+    kv_layout, and assigning them rewrites it (they used to be read-only properties)."""
+    from tgis_amd.models.causal_lm import CausalLMBatch, KVLayout
+
+    b = CausalLMBatch.__new__(CausalLMBatch)
+    b.kv_layout = KVLayout()
+    assert b.keys_head_dim_last is True and b.merged_kv_cache is False
+    b.keys_head_dim_last = False
+    assert b.kv_layout == KVLayout(keys_time_last=True) and b.keys_head_dim_last is False
+    b.merged_kv_cache = True
+    assert b.kv_layout == KVLayout(merged=True, keys_time_last=True) and b.merged_kv_cache is True

@@ -14,7 +14,7 @@ void tgis_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" const char* tgis_version(void) { return "tgis_hip 0.1 (gfx950)"; }
+extern "C" const char* tgis_version(void) { return "tgis_hip 0.5 (gfx950)"; }
 extern "C" const char* tgis_arch(void) { return "gfx950"; }
 extern "C" const char* tgis_last_error(void) { return g_err; }
 extern "C" void tgis_clear_error(void) {

@@ -563,6 +563,7 @@ static void launch_attn_nw(const AttnArgs& a, dim3 grid, hipStream_t st, int nw)
     if (nw == 2) return launch_attn_one<T, D, 2, CH>(a, grid, st);
     if constexpr (CH == 1) {  // wide blocks: few (sequence, kv head) groups, the waves of one block share the keys
         if (nw == 8) return launch_attn_one<T, D, 8, CH>(a, grid, st);
+        if (nw == 3) return launch_attn_one<T, D, 3, CH>(a, grid, st);  // three waves per SIMD at 1024 blocks (A/B hook)
     }
     launch_attn_one<T, D, 4, CH>(a, grid, st);
 }
@@ -647,6 +648,7 @@ struct CounterPool {
     hipStream_t owner[ATTN_COUNTER_SETS] = {};
     uint64_t last_use[ATTN_COUNTER_SETS] = {};  // launch stamp: the least recently used slot is handed to a new stream
     bool in_graph[ATTN_COUNTER_SETS] = {};      // a captured graph holds this slot's pointer: it never changes hands
+    int pending[ATTN_COUNTER_SETS] = {};        // handed out, launch not enqueued yet: an idle owner stream proves nothing
     uint64_t stamp = 0;
     int used = 0;
     bool ready = false;
@@ -655,11 +657,16 @@ struct CounterPool {
 std::mutex g_attn_counters_mu;
 std::map<int, CounterPool> g_attn_counters;
 
-unsigned* attn_counters(hipStream_t st) {
+// `slot` receives the index to give back with attn_counters_enqueued() once the launch that uses the array is in its
+// stream (between this call and the launch a second host thread could see the new owner's stream idle and take
+// the same array).
+unsigned* attn_counters(hipStream_t st, int* dev_out, int* slot) {
+    *slot = -1;
     static const bool off = getenv("TGIS_ATTN_FUSED_COMBINE") && atoi(getenv("TGIS_ATTN_FUSED_COMBINE")) == 0;
     if (off) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    *dev_out = dev;
     std::lock_guard<std::mutex> lock(g_attn_counters_mu);
     CounterPool& pool = g_attn_counters[dev];
     if (!pool.ready) {
@@ -680,17 +687,23 @@ unsigned* attn_counters(hipStream_t st) {
     }
     ++pool.stamp;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    const bool query_failed = hipStreamIsCapturing(st, &cs) != hipSuccess;
+    if (query_failed) (void)hipGetLastError();  // not this launch's error: do not leave it for TGIS_CHECK_LAUNCH
+    const bool capturing = query_failed || cs != hipStreamCaptureStatusNone;
     for (int i = 0; i < pool.used; ++i)
         if (pool.owner[i] == st) {
             pool.last_use[i] = pool.stamp;
             pool.in_graph[i] |= capturing;
+            ++pool.pending[i];
+            *slot = i;
             return pool.sets[i];
         }
     if (pool.used < ATTN_COUNTER_SETS) {
         pool.owner[pool.used] = st;
         pool.last_use[pool.used] = pool.stamp;
         pool.in_graph[pool.used] = capturing;
+        ++pool.pending[pool.used];
+        *slot = pool.used;
         return pool.sets[pool.used++];
     }
     // All slots are owned.  A slot whose stream has no launch in flight can change hands (its counters are zero between
@@ -699,7 +712,7 @@ unsigned* attn_counters(hipStream_t st) {
     // (a slot whose pointer sits in a captured graph stays where it is: the graph replays on streams this pool never sees)
     int lru = -1;
     for (int i = 0; i < ATTN_COUNTER_SETS; ++i)
-        if (!pool.in_graph[i] && (lru < 0 || pool.last_use[i] < pool.last_use[lru])) lru = i;
+        if (!pool.in_graph[i] && pool.pending[i] == 0 && (lru < 0 || pool.last_use[i] < pool.last_use[lru])) lru = i;
     hipStreamCaptureStatus ocs = hipStreamCaptureStatusNone;
     // (a query on a stream that is being captured would invalidate its capture: ask that first)
     const bool owner_capturing = lru < 0 || hipStreamIsCapturing(pool.owner[lru], &ocs) != hipSuccess ||
@@ -707,6 +720,8 @@ unsigned* attn_counters(hipStream_t st) {
     if (!capturing && !owner_capturing && hipStreamQuery(pool.owner[lru]) == hipSuccess) {
         pool.owner[lru] = st;
         pool.last_use[lru] = pool.stamp;
+        ++pool.pending[lru];
+        *slot = lru;
         return pool.sets[lru];
     }
     (void)hipGetLastError();
@@ -717,6 +732,15 @@ unsigned* attn_counters(hipStream_t st) {
     }
     return nullptr;
 }
+void attn_counters_enqueued(int dev, int slot) {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_attn_counters_mu);
+    --g_attn_counters[dev].pending[slot];
+}
+struct CounterLease {  // gives the slot back when the launch is in its stream (or the call fails before it)
+    int dev = 0, slot = -1;
+    ~CounterLease() { attn_counters_enqueued(dev, slot); }
+};
 }  // namespace
 
 namespace {
@@ -790,6 +814,7 @@ static int attn_paged_impl(const void* q, int64_t ld_q, const void* k_pool, cons
     a.slots = fr ? fr->slots : nullptr;
     a.rot = fr ? fr->rot : 0;
     int64_t total_q = 0;
+    CounterLease lease;
     if (num_splits > 1) {
         // total q tokens is only needed to size the split workspace; callers pass B*max_q_len rows
         total_q = B * max_q_len;
@@ -802,7 +827,7 @@ static int attn_paged_impl(const void* q, int64_t ld_q, const void* k_pool, cons
         const int64_t recs = fused_records(B, H, Hkv, num_splits);
         const int64_t groups = B * Hkv * a.HCB;
         if (groups <= ATTN_COUNTERS && recs * D * 4 < (1ll << 31) && ch == 1) {
-            a.counters = attn_counters(st);
+            a.counters = attn_counters(st, &lease.dev, &lease.slot);
             if (a.counters) a.ws_ml = a.ws_o + recs * D;
         }
     }
@@ -827,8 +852,8 @@ static int attn_paged_impl(const void* q, int64_t ld_q, const void* k_pool, cons
     if (max_q_len == 1 && wide_decode_blocks(nblocks / num_splits, ch)) nw = 8;
     if (const char* e = getenv("TGIS_ATTN_NW")) {
         const int v = atoi(e);
-        nw = (v == 1 || v == 2 || v == 8) ? v : 4;
-        if (ch > 1 && nw > 4) nw = 4;
+        nw = (v == 1 || v == 2 || v == 3 || v == 8) ? v : 4;
+        if (ch > 1 && (nw > 4 || nw == 3)) nw = 4;
     }
     TgisTimedScope timed(TGIS_OP_ATTN, st);
     if (dtype == TGIS_F16) {

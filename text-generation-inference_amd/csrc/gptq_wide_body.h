@@ -79,6 +79,15 @@ static inline int64_t wide_blocks(int64_t K, int64_t N, int act, int64_t M = 32)
     const WidePlan p = plan_wide(K, N, act, M);
     return cdiv64(cdiv64(N, 32), p.CT) * p.S;
 }
+// k64-steps that each wave of a block's older half takes over from its partner in the younger half (gptq_wide_unit).
+// Measured on the cfg3 shapes (tools/floor/wide.hip `kb`, profiles/r05_wide_kbias.log): the younger half runs ~2 steps behind
+// when a wave has 8 steps, ~1 when it has 2 - 5.
+static inline int wide_kbias(int64_t K, int S) {
+    static const int ov = getenv("TGIS_GPTQ_WIDE_KBIAS") ? atoi(getenv("TGIS_GPTQ_WIDE_KBIAS")) : -1;  // tuning hook
+    if (ov >= 0) return ov;
+    const int64_t per_wave = (K / 64) / std::max(S, 1) / WIDE_WK;
+    return per_wave >= 6 ? 1 : 0;
+}
 // the largest split count either row class (<= 32, <= 64) may use: what slab buffers are sized for
 static inline int wide_max_splits(int64_t K, int64_t N) { return std::max(plan_wide(K, N, 0, 32).S, plan_wide(K, N, 0, 64).S); }
 
@@ -88,6 +97,12 @@ static inline int wide_max_splits(int64_t K, int64_t N) { return std::max(plan_w
 template <int CT, int ACT, bool OUTF, int MR>
 __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char* smem) {
     constexpr int WK = WIDE_WK, DEPTH = WIDE_DEPTH, NR = 16 / WK;
+    {   // every cache line of the argument block is requested at entry: one scalar round trip instead of three dependent
+        // ones before the first weight request (tools/floor/wide.hip `pre`: 0.1 - 0.25 us per launch)
+        const int64_t l0 = a.ldo;
+        const int l1 = a.S, l2 = a.rD;
+        asm volatile("" ::"s"(l0), "s"(l1), "s"(l2));
+    }
     const int lane = threadIdx.x & 63;
     const int wk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cg = blockIdx.x, split = blockIdx.y;
@@ -95,7 +110,15 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
     const int sp_len = (steps + a.S - 1) / a.S;
     const int sb = split * sp_len, se = min(steps, sb + sp_len);
     const int len = max(se - sb, 0);
-    const int s0 = sb + (len * wk) / WK, s1 = sb + (len * (wk + 1)) / WK;  // this wave's k64-steps (may be empty)
+    // This wave's k64-steps (may be empty).  The split is NOT even (round 5): the four waves that the CU launched first
+    // (k-parts 0 .. 3) request their prologue first, the younger four queue behind them in the CU's 64 B/clk address path
+    // (2.4 k ticks later at the cfg3 shapes) and stay behind through the loop, so everybody waited ~3 k ticks for them at the
+    // k-part exchange (profiles/r05_wide_timeline.log, medians by wave index).  Every older wave takes a.kbias steps over from
+    // its younger partner: boundaries f(w) = len w / WK + kb (min(w, WK/2) - max(w - WK/2, 0)).  The order in which the
+    // k-parts are summed stays fixed, so the result stays deterministic.
+    const int kb = min(a.kbias, max(len / WK - 1, 0));
+    const int s0 = sb + (len * wk) / WK + kb * (min(wk, WK / 2) - max(wk - WK / 2, 0));
+    const int s1 = sb + (len * (wk + 1)) / WK + kb * (min(wk + 1, WK / 2) - max(wk + 1 - WK / 2, 0));
     const int mrows = a.M;  // 1 .. 32 MR
 
     const char* wt[CT];

@@ -23,6 +23,7 @@ transformers >= 4.4x), the BLOOM-era pair with flattened heads and transposed ke
 `[B, T, C]` of older GPT-BigCode (`CombinedKVCausalLMBatch`, :750-756).  Every membership operation below touches the
 cache only through the layout's time axis, so the three share one code path (the reference branches per layout:
 :337-442, :504-509, :528-545, :722-729)."""
+import dataclasses
 import inspect
 import logging
 import os
@@ -117,13 +118,23 @@ class CausalLMBatch(Batch):
     kv_layout: KVLayout = KVLayout()
 
     # the reference's names for the two layout flags (causal_lm.py:54-57)
+    # (assignable, as the reference's plain attributes are: its KeysDimTransposed / CombinedKV from_pb set them, and so
+    # may an external subclass; kv_layout stays the one source of truth)
     @property
     def keys_head_dim_last(self) -> bool:
         return not self.kv_layout.keys_time_last
 
+    @keys_head_dim_last.setter
+    def keys_head_dim_last(self, value: bool) -> None:
+        self.kv_layout = dataclasses.replace(self.kv_layout, keys_time_last=not value)
+
     @property
     def merged_kv_cache(self) -> bool:
         return self.kv_layout.merged
+
+    @merged_kv_cache.setter
+    def merged_kv_cache(self, value: bool) -> None:
+        self.kv_layout = dataclasses.replace(self.kv_layout, merged=bool(value))
 
     def get_id(self) -> int:
         return self.batch_id

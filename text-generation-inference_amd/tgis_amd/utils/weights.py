@@ -9,12 +9,15 @@ to its Triton kernel, weights.py:150-156; this build has no second kernel family
 
 `DictWeights` serves the same interface from an in-memory dict (synthetic benchmark weights and tests)."""
 import json
+import logging
 import math
 import os
 from pathlib import Path
 from typing import Any, Dict, List, Optional, Tuple
 
 import torch
+
+logger = logging.getLogger(__name__)
 
 QUANTIZE_CONFIG_FILENAME = "quantize_config.json"
 
@@ -143,6 +146,10 @@ class _Base:
         uniq, counts = torch.unique_consecutive(g[order], return_counts=True)
         padded = (counts + SUB - 1) // SUB * SUB
         Kp = int(padded.sum())
+        # every group present in the shard costs up to SUB - 1 pad rows: at high TP degree K' approaches 2 K (image, streamed
+        # bytes and the scale table grow alike; the numerics do not change) — say so once per weight
+        logger.info("%s: act-order row shard of %d rows in %d groups -> %d padded rows (K'/K = %.2f)", prefix, rows,
+                    int(uniq.numel()), Kp, Kp / max(rows, 1))
         perm = torch.full((Kp,), -1, dtype=torch.int32)
         parent = torch.empty(Kp // SUB, dtype=torch.int64)
         pos = src = 0

@@ -540,7 +540,12 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
 //            anybody's second);
 //   EPI      0 plain; 20 SiLU * up on the interleaved image, row-major; 21 the same in fragment order (2-byte stores, the
 //            product's OUTF); 22 fragment order through LDS: 16-byte stores.
-template <int CT, int WK, int DW, int DX, int ORD, int PRIO, int PRE, bool TR, int KB = 0, int PB = 0, int EPI = 0>
+//   AR 1     "lean" arithmetic for group size 128 (two k64-steps per group, wave ranges aligned to groups): the B operand is the
+//            raw nibble as 1024 + q (low positions) / 64 + q (high positions): 5 VALU per 8 weights instead of 13; offsets and
+//            zero point leave through ONE more MFMA per tile and group whose A operand carries the lane's partial row sums of
+//            x over the two position classes (hi + lo f16 parts, v_dot2 from the fragments already in registers) and whose B
+//            operand is {-zc, -zc, zd, zd}; the group's scale is applied to the group's fp32 sum (16 fma per tile and group).
+template <int CT, int WK, int DW, int DX, int ORD, int PRIO, int PRE, bool TR, int KB = 0, int PB = 0, int EPI = 0, int AR = 0>
 __global__ __launch_bounds__(64 * WK) void wide2_gemm(Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(DW % DX == 0, "the activation ring divides the weight ring");
@@ -635,11 +640,59 @@ __global__ __launch_bounds__(64 * WK) void wide2_gemm(Args a) {
             }
         }
     };
+    f32x16 accg[AR ? CT : 1];
+    float SL = 0.f, SH = 0.f;
+    uint32_t EXH = 0x54005400u;
+    asm volatile("" : "+v"(EXH));
+    auto consume_lean = [&](int d) {
+        static_assert(!AR || (DW == 2 && DX == 2), "lean arithmetic: the ring is one group");
+        const f16x2 one = {(f16)1.f, (f16)1.f};
+        if (d == 0) { SL = 0.f; SH = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4 xu = __builtin_bit_cast(u32x4, xa[d][i]);
+            SL = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, xu[0]), one, SL, false);
+            SH = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, xu[1]), one, SH, false);
+            SL = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, xu[2]), one, SL, false);
+            SH = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, xu[3]), one, SH, false);
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t q = wq[d][t][i], q2 = q >> 8;
+                const u32x4 raw = {and_or(q, M0r, EXr), and_or(q, M1r, EXH), and_or(q2, M0r, EXr), and_or(q2, M1r, EXH)};
+                if (d == 0 && i == 0)
+                    accg[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[d][i], __builtin_bit_cast(f16x8, raw),
+                                                                     f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+                else
+                    accg[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[d][i], __builtin_bit_cast(f16x8, raw), accg[t], 0, 0, 0);
+            }
+        }
+        if (d == 1) {
+            const f16 slh = (f16)SL, shh = (f16)SH;
+            const f16 sll = (f16)(SL - (float)slh), shl = (f16)(SH - (float)shh);
+            const f16x2 a0 = {slh, sll}, a1 = {shh, shl};
+            const u32x4 ae = {__builtin_bit_cast(uint32_t, a0), __builtin_bit_cast(uint32_t, a1), 0u, 0u};
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const f16x2 szh = __builtin_bit_cast(f16x2, sz[d][t]);
+                const f16 nzc = -szh[1], zd1 = (f16)960.f - szh[1];
+                const f16x2 b0 = {nzc, nzc}, b1 = {zd1, zd1};
+                const u32x4 be = {__builtin_bit_cast(uint32_t, b0), __builtin_bit_cast(uint32_t, b1), 0u, 0u};
+                accg[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ae), __builtin_bit_cast(f16x8, be), accg[t], 0, 0, 0);
+                const float sf = (float)szh[0];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = __builtin_fmaf(sf, accg[t][r], acc[t][r]);
+            }
+        }
+    };
     STAMP(1);
     int s = s0;
     for (; s + DW < s1; s += DW) {
 #pragma unroll
         for (int d = 0; d < DW; ++d) {
+            if (AR) consume_lean(d); else
             consume(d);
             __builtin_amdgcn_sched_barrier(0);
             load_w(d, s + d + DW);
@@ -651,7 +704,7 @@ __global__ __launch_bounds__(64 * WK) void wide2_gemm(Args a) {
     // the last group: the steps that exist; the activation ring is shorter than the weight ring, so it is still refilled
 #pragma unroll
     for (int d = 0; d < DW; ++d) {
-        if (s + d < s1) consume(d);
+        if (s + d < s1) { if (AR) consume_lean(d); else consume(d); }
         if (d + DX < DW) {
             __builtin_amdgcn_sched_barrier(0);
             load_x(d % DX, s + d + DX);
@@ -928,7 +981,7 @@ static float run(const Image& im, const std::vector<uint8_t*>& sets, const f16* 
 
 // ---- round 5 runner: wide2_gemm, timed as back-to-back launches over rotating weight sets; WIDE_TRACE=1 adds the per-wave
 // timeline, overall and by wave index (is the arrival skew systematic by wave age?)
-template <int CT, int WK, int DW, int DX, int ORD = 1, int PRIO = 0, int PRE = 0, int KB = 0, int PB = 0, int EPI = 0>
+template <int CT, int WK, int DW, int DX, int ORD = 1, int PRIO = 0, int PRE = 0, int KB = 0, int PB = 0, int EPI = 0, int AR = 0>
 static float run2(const Image& im, const std::vector<uint8_t*>& sets, const f16* dx, f16* dout, float* dslabs, int M, int S,
                   int iters, const std::vector<f16>& hx) {
     Args a;
@@ -941,8 +994,9 @@ static float run2(const Image& im, const std::vector<uint8_t*>& sets, const f16*
     a.spg_shift = sh;
     const int cgs = (im.NT + CT - 1) / CT;
     const size_t lds = (size_t)WK * CT * 4096 + (EPI == 22 ? 32 * CT * 16 * 2 : 0);
-    auto kern = wide2_gemm<CT, WK, DW, DX, ORD, PRIO, PRE, false, KB, PB, EPI>;
-    auto kern_tr = wide2_gemm<CT, WK, DW, DX, ORD, PRIO, PRE, true, KB, PB, EPI>;
+    auto kern = wide2_gemm<CT, WK, DW, DX, ORD, PRIO, PRE, false, KB, PB, EPI, AR>;
+    auto kern_tr = wide2_gemm<CT, WK, DW, DX, ORD, PRIO, PRE, true, KB, PB, EPI, AR>;
+    if (AR && ((im.K / 64 / S) % (2 * WK) != 0 || im.gs != 128 || KB)) { printf("  (lean arithmetic needs whole groups per wave: skipped)\n"); return 0.f; }
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute((const void*)kern_tr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int occ = 0;
@@ -982,6 +1036,7 @@ static float run2(const Image& im, const std::vector<uint8_t*>& sets, const f16*
     }
     const int blocks = cgs * S;
     const double mb = (double)(im.offB * 1.0 * (im.K / 64) / im.KS + (double)im.NT * im.G * 128) / 1e6;
+    if (AR) printf("  [lean]");
     printf("  CT %d WK %2d DW %d DX %d S %2d ord %d prio %d pre %d kb %d pb %d epi %2d: blocks %4d (%d/CU fit)  %6.2f us  %5.2f TB/s  relerr %.1e%s\n", CT, WK, DW, DX, S, ORD,
            PRIO, PRE, KB, PB, EPI, blocks, occ, best, mb / best, maxerr, maxerr > 3e-3 ? "  <-- WRONG" : "");
     if (getenv("WIDE_TRACE")) {
@@ -1118,8 +1173,24 @@ int main(int argc, char** argv) {
                 R2(2, 8, 2, 2, 4, 1, 1, 1, 1); R2(2, 8, 2, 2, 4, 1, 0, 1, 0, 1); R2(2, 8, 2, 2, 4, 1, 0, 1, 1, 1); R2(2, 8, 2, 2, 3, 1, 0, 1, 1); R2(2, 8, 2, 2, 3, 1, 0, 1, 2);
                 R2(2, 8, 2, 2, 2, 1, 0, 1, 2); R2(2, 8, 2, 2, 2, 1, 0, 1, 3);
             }
+        } else if (!strcmp(suite, "r05c")) {   // lean arithmetic against the exact dequantisation, same skeleton
+            if (sh.N == 12288) {
+                R2(2, 8, 2, 2, 1, 1, 0, 1); R2(2, 8, 2, 2, 1, 1, 0, 1, 0, 0, 0, 1); R2(3, 8, 2, 2, 1, 1, 0, 1, 0, 0, 0, 1); R2(2, 4, 2, 2, 1, 1, 0, 1, 0, 0, 0, 1);
+            } else if (sh.N == 22016) {
+                R2(3, 8, 2, 2, 1, 1, 0, 1); R2(3, 8, 2, 2, 1, 1, 0, 1, 0, 0, 0, 1); R2(4, 8, 2, 2, 1, 1, 0, 1, 0, 0, 0, 1); R2(2, 8, 2, 2, 1, 1, 0, 1, 0, 0, 0, 1);
+                R2(3, 8, 2, 2, 1, 1, 0, 1, 0, 0, 21); R2(3, 8, 2, 2, 1, 1, 0, 1, 0, 0, 21, 1);
+            } else if (sh.K == 4096) {
+                R2(2, 8, 2, 2, 4, 1, 0, 1); R2(2, 8, 2, 2, 4, 1, 0, 1, 0, 0, 0, 1); R2(2, 8, 2, 2, 2, 1, 0, 1, 0, 0, 0, 1);
+            } else {
+                R2(2, 8, 2, 2, 4, 1, 0, 1);
+            }
         } else if (!strcmp(suite, "r05t")) {   // run with WIDE_TRACE=1: timelines of the shipped plans and of the deeper weight ring
-            if (getenv("WIDE_T2")) {   // second trace set: the weighted split
+            if (getenv("WIDE_T3")) {   // third trace set: lean arithmetic
+                if (sh.N == 12288) { R2(2, 8, 2, 2, 1, 1, 0, 1, 0, 0, 0, 1); }
+                else if (sh.N == 22016) { R2(3, 8, 2, 2, 1, 1, 0, 1, 0, 0, 0, 1); }
+                else if (sh.K == 4096) { R2(2, 8, 2, 2, 4, 1, 0, 1, 0, 0, 0, 1); }
+            }
+            else if (getenv("WIDE_T2")) {   // second trace set: the weighted split
                 if (sh.N == 12288) { R2(2, 8, 2, 2, 1, 1, 0, 1, 1); R2(2, 8, 2, 2, 1, 1, 0, 1, 2); }
                 else if (sh.N == 22016) { R2(3, 8, 2, 2, 1, 1, 0, 1, 1); R2(3, 8, 2, 2, 1, 1, 0, 1, 2); R2(3, 8, 2, 2, 1, 1, 0, 1, 1, 0, 22); }
                 else { R2(2, 8, 2, 2, 4, 1, 0, 1, 1); }
