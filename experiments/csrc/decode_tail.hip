@@ -527,7 +527,6 @@ int fill_gemm(GemmArgs& a, int& tw, int& gx, int& gy, const tgis_tail_linear& l,
     a.slabs = slabs;
     a.partial = partial;
     a.spg_shift = 30;
-    a.kbias = 0;
     a.err = nullptr;
     if (l.groups > 1)
         for (a.spg_shift = 0; (1 << a.spg_shift) < spg; ++a.spg_shift) {}

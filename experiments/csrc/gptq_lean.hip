@@ -136,7 +136,6 @@ int launch_lean(const void* x, int64_t ldx, const float* xs, int64_t ldxs, const
     a.slabs = slabs;
     a.partial = partial;
     a.spg_shift = 1;
-    a.kbias = 0;
     a.err = nullptr;
     la.xs = xs;
     la.ldxs = ldxs;

@@ -36,6 +36,13 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     constexpr int KS = D / 32;  // k-steps of the QK^T MFMA
     constexpr int NB = D / 16;  // 16-row blocks of O^T
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    {   // every cache line of the argument block the decode path reads is requested at entry (one scalar round trip instead
+        // of one per group of fields: tools/floor/wide.hip `pre`)
+        const int64_t l0 = a.ld_q;
+        const int l1 = a.NS;
+        const void* l2 = a.counters;
+        asm volatile("" ::"s"(l0), "s"(l1), "s"(l2));
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: the block-table reads become scalar loads
     const int col = lane & 15, c = lane >> 4;
@@ -251,6 +258,9 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     // pages below kfull are visible in full to every column of the tile (the tile's first token sees kfull keys)
     const int kfull = ctx - q_len + t0 + 1;
     int p = pbeg + w;
+    // the first fully visible page's table entry is asked for HERE, in front of the partly visible pages: behind them it was
+    // a scalar round trip with nothing of this wave in flight
+    const int pg_first = (p < pend) ? btrow[p] : 0;
     // The partly visible pages of this wave (decode: the sequence's last page) go FIRST (round 4): the softmax is order-
     // independent, and their masked body is a second copy of the page code that each wave runs once — at the end of the
     // launch its instruction fetch and its un-overlapped load were part of every block's tail (ctx 1023 vs 1024: +2.6 us
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
         const int npairs = p < pend ? nfull >> 1 : 0;
         if (npairs > 0) {
             V8 kfa[2][KS], vfa[NB], kfb[2][KS], vfb[NB];
-            load_page(btrow[p], kfa, vfa);
+            load_page(pg_first, kfa, vfa);
             for (int i = 0; i + 1 < npairs; ++i) {
                 load_page(btrow[p + NW], kfb, vfb);
                 apply_page(p, kfa, vfa, std::true_type{});
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     // the fully visible pages — a loop of their own, not one loop with both bodies: the register allocator sizes a loop
     // for the union of what its branches hold (180 vs 122 VGPRs here, i.e. 2 instead of 3 waves per SIMD, which costs
     // the HBM-bound many-block shapes 5 %)
-    int pg = (p < pend) ? btrow[p] : 0;
+    int pg = PIPE ? ((p < pend) ? btrow[p] : 0) : pg_first;
     for (; p < pend && p * 32 + 32 <= kfull; p += NW) {
         const int pg_next = (p + NW < pend) ? btrow[p + NW] : 0;
         V8 kf[2][KS], vf[NB];

@@ -539,7 +539,6 @@ static int launch_tall(const void* x, int64_t ldx, const void* prepared, const v
     a.slabs = slabs;
     a.partial = partial;
     a.spg_shift = 30;
-    a.kbias = 0;
     a.err = nullptr;
     a.positions = a.slots = nullptr;
     a.cosb = a.sinb = nullptr;
@@ -686,7 +685,6 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
     a.slabs = slabs;
     a.partial = partial;
     a.spg_shift = 30;
-    a.kbias = 0;
     a.err = nullptr;
     a.positions = a.slots = nullptr;
     a.cosb = a.sinb = nullptr;
@@ -712,7 +710,6 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
         // wide_plan_as_gemm_plan); checked by the caller: wide_serves(), act in {0, 2, 3}, no permutation
         const bool outf = ldo == TGIS_LD_FRAGMENTS;
         dim3 wgrid((unsigned)cdiv64(p.NT, pl.TN), (unsigned)pl.S);
-        a.kbias = gptq::wide_kbias(K, pl.S);
 #define TGIS_WIDE(CT)                                                                                   \
     do {                                                                                                \
         int rc_ = act == 3   ? launch_wide_one<CT, 3, false>(wgrid, st, a)                              \

@@ -77,7 +77,6 @@ struct GemmArgs {
     float* slabs;  // [Mslabs][S][32][NT*32] f32 partial sums (S > 1 or partial mode)
     int partial;   // 1: always leave fp32 slabs (deferred reduce), never write `out`
     int spg_shift; // GROUP64: log2(k64-steps per group) (30 when there is a single group)
-    int kbias;     // gptq_wide_unit: k64-steps each older wave of a block takes over from its younger partner (plan_wide)
     unsigned* err; // decode tail: word that receives a code when a bounded spin gives up (nullptr otherwise)
     // ACT == 3 (rope image): the epilogue rotates q / k heads and writes k / v into their cache pages; `out` is the q tensor
     const int32_t* positions;  // [M]

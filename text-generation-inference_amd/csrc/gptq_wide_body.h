@@ -79,15 +79,6 @@ static inline int64_t wide_blocks(int64_t K, int64_t N, int act, int64_t M = 32)
     const WidePlan p = plan_wide(K, N, act, M);
     return cdiv64(cdiv64(N, 32), p.CT) * p.S;
 }
-// k64-steps that each wave of a block's older half takes over from its partner in the younger half (gptq_wide_unit).
-// Measured on the cfg3 shapes (tools/floor/wide.hip `kb`, profiles/r05_wide_kbias.log): the younger half runs ~2 steps behind
-// when a wave has 8 steps, ~1 when it has 2 - 5.
-static inline int wide_kbias(int64_t K, int S) {
-    static const int ov = getenv("TGIS_GPTQ_WIDE_KBIAS") ? atoi(getenv("TGIS_GPTQ_WIDE_KBIAS")) : -1;  // tuning hook
-    if (ov >= 0) return ov;
-    const int64_t per_wave = (K / 64) / std::max(S, 1) / WIDE_WK;
-    return per_wave >= 6 ? 1 : 0;
-}
 // the largest split count either row class (<= 32, <= 64) may use: what slab buffers are sized for
 static inline int wide_max_splits(int64_t K, int64_t N) { return std::max(plan_wide(K, N, 0, 32).S, plan_wide(K, N, 0, 64).S); }
 
@@ -110,15 +101,11 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
     const int sp_len = (steps + a.S - 1) / a.S;
     const int sb = split * sp_len, se = min(steps, sb + sp_len);
     const int len = max(se - sb, 0);
-    // This wave's k64-steps (may be empty).  The split is NOT even (round 5): the four waves that the CU launched first
-    // (k-parts 0 .. 3) request their prologue first, the younger four queue behind them in the CU's 64 B/clk address path
-    // (2.4 k ticks later at the cfg3 shapes) and stay behind through the loop, so everybody waited ~3 k ticks for them at the
-    // k-part exchange (profiles/r05_wide_timeline.log, medians by wave index).  Every older wave takes a.kbias steps over from
-    // its younger partner: boundaries f(w) = len w / WK + kb (min(w, WK/2) - max(w - WK/2, 0)).  The order in which the
-    // k-parts are summed stays fixed, so the result stays deterministic.
-    const int kb = min(a.kbias, max(len / WK - 1, 0));
-    const int s0 = sb + (len * wk) / WK + kb * (min(wk, WK / 2) - max(wk - WK / 2, 0));
-    const int s1 = sb + (len * (wk + 1)) / WK + kb * (min(wk + 1, WK / 2) - max(wk + 1 - WK / 2, 0));
+    // This wave's k64-steps (may be empty).  (Round 5 measured an uneven split — the four waves a CU launches first run ~2 steps
+    // ahead of the younger four, which queue behind them in the address path — and a prologue barrier, a raised priority for
+    // the younger half and deeper weight rings: the block finishes when its CU has moved its bytes, however they are dealt;
+    // tools/floor/wide.hip `kb` / `pb` / `prio` / `DW`, profiles/r05_wide_kbias*.log, r05_wide_plans.log.)
+    const int s0 = sb + (len * wk) / WK, s1 = sb + (len * (wk + 1)) / WK;
     const int mrows = a.M;  // 1 .. 32 MR
 
     const char* wt[CT];
@@ -257,11 +244,16 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
 #pragma unroll
       for (int tg0 = 0; tg0 < CT; tg0 += TG) {
         if (mr > 0 || tg0 > 0) __syncthreads();  // the previous group's sums have been read
+        // (round 5: register PAIRS — [k-part][tile][register / 2][lane][2] — so that the sixteen registers leave as eight
+        // ds_write_b64 and the two registers a wave finishes come back as one ds_read_b64 per k-part and tile: the exchange
+        // moves 2 x 8 waves x CT x 4 KiB through an LDS that takes 64 B/clk of 4-byte stores and gives 128 B/clk of 4-byte
+        // loads, ~2.3 k clocks at CT 3; 8-byte accesses take 85 and 256 B/clk.  Same values, same order of the sum.)
+        static_assert(NR == 2, "the pair layout is for eight k-parts");
 #pragma unroll
         for (int t = tg0; t < tg0 + TG && t < CT; ++t) {
-            float* dst = red + ((wk * TG + (t - tg0)) << 10) + lane;
+            f32x2* dst = reinterpret_cast<f32x2*>(red + ((wk * TG + (t - tg0)) << 10)) + lane;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[r << 6] = acc[mr][t][r];
+            for (int rp = 0; rp < 8; ++rp) dst[rp << 6] = f32x2{acc[mr][t][2 * rp], acc[mr][t][2 * rp + 1]};
         }
         __syncthreads();
         float fin[CT][NR];
@@ -269,9 +261,9 @@ __device__ __forceinline__ void gptq_wide_unit(const GemmArgs& a, unsigned char*
         for (int t = tg0; t < tg0 + TG && t < CT; ++t) {
 #pragma unroll
             for (int k2 = 0; k2 < WK; ++k2) {
-                const float* src = red + ((k2 * TG + (t - tg0)) << 10) + ((wk * NR) << 6) + lane;
+                const f32x2 v = (reinterpret_cast<const f32x2*>(red + ((k2 * TG + (t - tg0)) << 10)) + (wk << 6))[lane];
 #pragma unroll
-                for (int j = 0; j < NR; ++j) fin[t][j] = k2 == 0 ? src[j << 6] : fin[t][j] + src[j << 6];
+                for (int j = 0; j < NR; ++j) fin[t][j] = k2 == 0 ? v[j] : fin[t][j] + v[j];
             }
         }
 #pragma unroll

@@ -160,10 +160,15 @@ __global__ __launch_bounds__(64 * WK) void wide_gemm(Args a) {
     f16x8 wn[EPI == 11 ? DEPTH : 1][4];
     auto load_x = [&](int d, int step) {
         if (XF) {   // fragment-major activation: [step][i][lane][8 halves], 1 KiB per load
-            const char* p = reinterpret_cast<const char*>(a.xf) + (int64_t)min(step, sclamp) * 4096;
+            // (MODE 8: every wave re-reads step 0 — the same four KiB, resident in the CU's L1: the instructions without the L2 traffic;
+            //  MODE 9: only the first of the four loads is real)
+            const char* p = reinterpret_cast<const char*>(a.xf) + (MODE == 8 ? (int64_t)0 : (int64_t)min(step, sclamp) * 4096);
             PIN_SGPR(p);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xa[d][i] = *(const GLOBAL_AS f16x8*)(p + woff + i * 1024);
+            for (int i = 0; i < 4; ++i) {
+                if (MODE == 9 && i > 0) { xa[d][i] = xa[d][0]; continue; }
+                xa[d][i] = *(const GLOBAL_AS f16x8*)(p + woff + i * 1024);
+            }
             if (EPI == 11) {   // the norm weight of the same k slots: two distinct 16-byte pieces per load
                 const char* q = reinterpret_cast<const char*>(a.normw) + (int64_t)min(step, sclamp) * 128;
                 PIN_SGPR(q);
@@ -650,18 +655,21 @@ __global__ __launch_bounds__(64 * WK) void wide2_gemm(Args a) {
         if (d == 0) { SL = 0.f; SH = 0.f; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const u32x4 xu = __builtin_bit_cast(u32x4, xa[d][i]);
-            SL = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, xu[0]), one, SL, false);
-            SH = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, xu[1]), one, SH, false);
-            SL = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, xu[2]), one, SL, false);
-            SH = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, xu[3]), one, SH, false);
+            // (element pairs, NOT __builtin_bit_cast(f16x2, <element of a u32x4>): hipcc 7.2 folds the four of them onto dword 0)
+            const f16x8 xv = xa[d][i];
+            SL = __builtin_amdgcn_fdot2(f16x2{xv[0], xv[1]}, one, SL, false);
+            SH = __builtin_amdgcn_fdot2(f16x2{xv[2], xv[3]}, one, SH, false);
+            SL = __builtin_amdgcn_fdot2(f16x2{xv[4], xv[5]}, one, SL, false);
+            SH = __builtin_amdgcn_fdot2(f16x2{xv[6], xv[7]}, one, SH, false);
         }
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t q = wq[d][t][i], q2 = q >> 8;
-                const u32x4 raw = {and_or(q, M0r, EXr), and_or(q, M1r, EXH), and_or(q2, M0r, EXr), and_or(q2, M1r, EXH)};
+                // plain C, not the asm and_or: hipcc does not pad an asm VALU result that an MFMA reads next (DESIGN.md section 6,
+                // round 3: stale rows); the same expression in C compiles to v_and_or_b32 with the hazard handled
+                const u32x4 raw = {(q & M0r) | EXr, (q & M1r) | EXH, (q2 & M0r) | EXr, (q2 & M1r) | EXH};
                 if (d == 0 && i == 0)
                     accg[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[d][i], __builtin_bit_cast(f16x8, raw),
                                                                      f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
@@ -1172,6 +1180,18 @@ int main(int argc, char** argv) {
                 R2(2, 8, 2, 2, 4); R2(2, 8, 2, 2, 4, 1, 0, 0, 1); R2(2, 8, 2, 2, 4, 1, 0, 0, 2); R2(2, 8, 2, 2, 4, 1, 0, 1, 1); R2(2, 8, 2, 2, 4, 1, 0, 1, 2);
                 R2(2, 8, 2, 2, 4, 1, 1, 1, 1); R2(2, 8, 2, 2, 4, 1, 0, 1, 0, 1); R2(2, 8, 2, 2, 4, 1, 0, 1, 1, 1); R2(2, 8, 2, 2, 3, 1, 0, 1, 1); R2(2, 8, 2, 2, 3, 1, 0, 1, 2);
                 R2(2, 8, 2, 2, 2, 1, 0, 1, 2); R2(2, 8, 2, 2, 2, 1, 0, 1, 3);
+            }
+        } else if (!strcmp(suite, "r05d")) {   // what bounds the loop?  ablations of the round-4 kernel (wrong results by design)
+            // 0 full; 1 no arithmetic; 2 no x loads; 6 no dequantisation; 5 weights + scales only; 4 weights only;
+            // 8 x always from the same 4 KiB (L1 hits); 9 one x load per step instead of four
+            if (sh.N == 12288) {
+                RM(2, 8, 2, 1, 0); RM(2, 8, 2, 1, 1); RM(2, 8, 2, 1, 2); RM(2, 8, 2, 1, 6); RM(2, 8, 2, 1, 5); RM(2, 8, 2, 1, 4); RM(2, 8, 2, 1, 8); RM(2, 8, 2, 1, 9);
+            } else if (sh.N == 22016) {
+                RM(3, 8, 2, 1, 0); RM(3, 8, 2, 1, 1); RM(3, 8, 2, 1, 2); RM(3, 8, 2, 1, 6); RM(3, 8, 2, 1, 5); RM(3, 8, 2, 1, 4); RM(3, 8, 2, 1, 8); RM(3, 8, 2, 1, 9);
+            } else if (sh.K == 4096) {
+                RM(2, 8, 2, 4, 0); RM(2, 8, 2, 4, 1); RM(2, 8, 2, 4, 2); RM(2, 8, 2, 4, 5); RM(2, 8, 2, 4, 4); RM(2, 8, 2, 4, 8); RM(2, 8, 2, 4, 9);
+            } else {
+                RM(2, 8, 2, 4, 0); RM(2, 8, 2, 4, 1); RM(2, 8, 2, 4, 2); RM(2, 8, 2, 4, 5); RM(2, 8, 2, 4, 4); RM(2, 8, 2, 4, 8); RM(2, 8, 2, 4, 9);
             }
         } else if (!strcmp(suite, "r05c")) {   // lean arithmetic against the exact dequantisation, same skeleton
             if (sh.N == 12288) {

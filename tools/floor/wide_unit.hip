@@ -66,7 +66,6 @@ static void run(const char* name, int K, int N, int S, int M) {
     a.x = dx; a.ldx = 0; a.offB = im.offB; a.out = dout; a.ldo = ACT == 2 ? N / 2 : N; a.M = M; a.K = K; a.N = N;
     a.G = im.G; a.gs = 128; a.S = S; a.NT = im.NT; a.KS = im.KS; a.slabs = dslabs; a.partial = S > 1;
     a.spg_shift = 1;
-    a.kbias = 0;
     const int cgs = (im.NT + CT - 1) / CT;
     const size_t lds = gptq::wide_lds_bytes(CT);
     auto kern = unit_kernel<CT, ACT, false, MR>;
