@@ -106,7 +106,9 @@ def test_deferred_reduce_plan_follows_the_row_class(nat, gpu_device, order):
     assert len(w.partial_plan) == 2, "one cached plan per row class"
 
 
-@pytest.mark.parametrize("M,K,I", [(32, 4096, 11008), (9, 1024, 1408), (32, 2048, 5632), (64, 4096, 11008), (45, 8192, 3584)])
+@pytest.mark.parametrize("M,K,I", [(32, 4096, 11008), (9, 1024, 1408), (32, 2048, 5632), (64, 4096, 11008), (45, 8192, 3584),
+                                   (64, 8192, 3584),   # 70B shard at TP = 8: two k splits, SiLU * up in the reduce launch
+                                   (32, 4096, 1376)])  # 7B shard at TP = 8: 86 one-tile blocks, unsplit
 def test_fragment_gemm_silu_epilogue_and_fragment_output(nat, gpu_device, M, K, I):
     """gate_up on the interleaved image with a fragment-order operand: row-major and fragment-order outputs hold the same
     bits, and equal the row-major launch up to summation order."""

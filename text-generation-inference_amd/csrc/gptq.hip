@@ -718,7 +718,7 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
                              : launch_wide_one<CT, 0, false>(wgrid, st, a);                             \
         if (rc_ != TGIS_OK) return rc_;                                                                 \
     } while (0)
-        if (pl.TN == 4) TGIS_WIDE(4); else if (pl.TN == 3) TGIS_WIDE(3); else TGIS_WIDE(2);
+        if (pl.TN == 4) TGIS_WIDE(4); else if (pl.TN == 3) TGIS_WIDE(3); else if (pl.TN == 1) TGIS_WIDE(1); else TGIS_WIDE(2);
 #undef TGIS_WIDE
         TGIS_CHECK_LAUNCH();
         if (!partial && pl.S > 1) {
@@ -813,8 +813,8 @@ static int check_gemm_args(const void* x, int64_t ldx, const void* prepared, int
 }
 
 // the fragment-order kernel's plan in the GemmPlan that launch_gptq takes (TN = column tiles per wave, S = k splits)
-static GemmPlan wide_plan_as_gemm_plan(int64_t K, int64_t N, int act, int64_t M) {
-    const gptq::WidePlan w = gptq::plan_wide(K, N, act, M);
+static GemmPlan wide_plan_as_gemm_plan(int64_t K, int64_t N, int act, int64_t M, bool finished = false) {
+    const gptq::WidePlan w = gptq::plan_wide(K, N, act, M, finished);
     return {0, w.S, gptq::WIDE_WK, w.CT, 1};
 }
 
@@ -831,7 +831,7 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
         TGIS_CHECK_ARG(!perm, "tgis_gptq_gemm_f16: act-order matrices take a row-major activation");
         TGIS_CHECK_ARG(ldo != TGIS_LD_FRAGMENTS || (act == 2 && (N / 2) % 64 == 0),
                        "tgis_gptq_gemm_f16: only the act = 2 output (N / 2 a multiple of 64) can leave in fragment order");
-        const GemmPlan wp = wide_plan_as_gemm_plan(K, N, act, M);
+        const GemmPlan wp = wide_plan_as_gemm_plan(K, N, act, M, /*finished=*/true);  // this entry point returns f16
         const int64_t need_w = 4096 + slab_bytes(M, N, wp.S);
         TGIS_CHECK_ARG(workspace && workspace_bytes >= need_w, "tgis_gptq_gemm_f16: workspace too small (%ld < %ld)",
                        (long)workspace_bytes, (long)need_w);
@@ -941,7 +941,11 @@ extern "C" int tgis_gptq_fragments_ok(int64_t M, int64_t K, int64_t N, int64_t g
     static const int64_t max_rows = getenv("TGIS_GPTQ_FRAGMENTS_MAX_ROWS") ? atoll(getenv("TGIS_GPTQ_FRAGMENTS_MAX_ROWS")) : 64;
     if (M > max_rows) return 0;
     static const int64_t min_blocks = getenv("TGIS_ROPE_MIN_BLOCKS") ? atoll(getenv("TGIS_ROPE_MIN_BLOCKS")) : 128;
-    if ((act == 2 || act == 3) && gptq::wide_blocks(K, N, act, M) < min_blocks) return 0;
+    // SiLU * up: from 64 blocks on (round 5, a 7B gate_up shard at TP = 8, 86 one-tile blocks: 8.2 us against 6.3 + 4.7 for
+    // the split streaming kernel + its reduce, profiles/r05_tp8_variants.log)
+    static const int64_t min_blocks_silu = getenv("TGIS_SILU_MIN_BLOCKS") ? atoll(getenv("TGIS_SILU_MIN_BLOCKS")) : 64;
+    if (act == 3 && gptq::wide_blocks(K, N, act, M) < min_blocks) return 0;
+    if (act == 2 && gptq::wide_blocks(K, N, act, M, true) < min_blocks_silu) return 0;
     return 1;
 }
 

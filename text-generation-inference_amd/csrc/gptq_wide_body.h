@@ -50,17 +50,28 @@ static inline bool wide_serves(int64_t M, int64_t K, int64_t N, int64_t groups, 
 // One block per CU where the shape allows it: column groups first (a wider group re-uses an A fragment more often), then
 // global k splits (fp32 slabs that the consumer sums) until ~256 blocks; at least one k64-step per wave.
 // act 2 / 3 (SiLU * up, rotary + cache write) finish their outputs in the epilogue: no split.
-static inline WidePlan plan_wide(int64_t K, int64_t N, int act, int64_t M = 32) {
+// Round 5 (tensor-parallel shard shapes): CT 1 where two tiles per wave would leave fewer than 128 blocks on an unsplit plan
+// (a shard's gate_up: 224 tiles = 112 blocks of two tiles, each taking in its whole M x K activation — 1 MB at 64 rows —
+// through one CU), and `finished` (the caller needs the f16 output, not slabs: row-parallel linears in front of an
+// all-reduce): unsplit whenever that still gives >= 128 blocks, because a split plan costs a reduce launch on top.
+static inline WidePlan plan_wide(int64_t K, int64_t N, int act, int64_t M = 32, bool finished = false) {
     if (const char* ov = getenv("TGIS_GPTQ_WIDE_PLAN")) {  // tuning hook: "CT,S"
         int ct = 0, sp = 0;
-        if (sscanf(ov, "%d,%d", &ct, &sp) == 2 && ct >= 2 && ct <= 4 && sp >= 1 && (sp == 1 || (act != 2 && act != 3)))
+        if (sscanf(ov, "%d,%d", &ct, &sp) == 2 && ct >= 1 && ct <= 4 && sp >= 1 && (sp == 1 || (act != 2 && act != 3)))
             return {ct, sp};
     }
+    static const bool ct1 = !(getenv("TGIS_GPTQ_WIDE_CT1") && atoi(getenv("TGIS_GPTQ_WIDE_CT1")) == 0);  // A/B hook
     const int64_t tiles = cdiv64(N, 32), steps = K / 64;
     int CT = 2;
     while (CT < 4 && cdiv64(tiles, CT) > 256) ++CT;
+    const bool unsplit = act == 2 || act == 3;
+    // (SiLU * up of a 64-row shard with a long k range — 70B gate_up at TP = 8, 224 one-tile blocks that each take in a 1 MiB
+    // activation, 20.3 us for 29 MB — was also run split over k with the activation in the reduce launch, CT x S = 1x2, 2x2,
+    // 4x4, 4x2, 2x4: none beat the unsplit plan on the rank step, profiles/r05_tp8_silu_plans.log.)
+    if (ct1 && tiles <= 256 && (unsplit ? cdiv64(tiles, 2) < 128 : (finished && tiles >= 128))) return {1, 1};
+    if (finished && !unsplit && cdiv64(tiles, CT) >= 128) return {CT, 1};
     int64_t S = 1;
-    if (act != 2 && act != 3) {
+    if (!unsplit) {
         const int64_t cgs = cdiv64(tiles, CT);
         S = std::max<int64_t>(1, (256 + cgs / 2) / cgs);
         S = std::min<int64_t>(S, std::max<int64_t>(1, steps / WIDE_WK));
@@ -75,12 +86,15 @@ static inline WidePlan plan_wide(int64_t K, int64_t N, int act, int64_t M = 32) 
     }
     return {CT, (int)S};
 }
-static inline int64_t wide_blocks(int64_t K, int64_t N, int act, int64_t M = 32) {
-    const WidePlan p = plan_wide(K, N, act, M);
+static inline int64_t wide_blocks(int64_t K, int64_t N, int act, int64_t M = 32, bool finished = false) {
+    const WidePlan p = plan_wide(K, N, act, M, finished);
     return cdiv64(cdiv64(N, 32), p.CT) * p.S;
 }
 // the largest split count either row class (<= 32, <= 64) may use: what slab buffers are sized for
-static inline int wide_max_splits(int64_t K, int64_t N) { return std::max(plan_wide(K, N, 0, 32).S, plan_wide(K, N, 0, 64).S); }
+static inline int wide_max_splits(int64_t K, int64_t N) {
+    return std::max(std::max(plan_wide(K, N, 0, 32).S, plan_wide(K, N, 0, 64).S),
+                    std::max(plan_wide(K, N, 0, 32, true).S, plan_wide(K, N, 0, 64, true).S));
+}
 
 // OUTF: the act = 2 output (the operand of the down projection) leaves in fragment order as well.
 // MR = 32-row blocks of the activation (1: M <= 32; 2: M <= 64 — every dequantised B fragment then feeds two MFMAs, the
