@@ -1,6 +1,7 @@
 """-m gpu: FULL-DEPTH parity at width.  tests/test_fullwidth_gpu.py runs one- and two-layer slices at workload batch and
 context; here the whole stack runs — Llama-2-7B int4 GPTQ, all 32 layers, and TinyLlama-1.1B bf16, all 22 — at a small
-batch (4 ragged prompts of up to ~100 tokens, three generate_token steps), so that what accumulates over depth in fp16 / bf16
+batch (4 ragged prompts of up to ~100 tokens — ~64 for the 7B, whose layer-major oracle is the slowest test of the suite —
+three generate_token steps), so that what accumulates over depth in fp16 / bf16
 is measured against the fp32 oracle: logits, token ids, logical KV slot indices, and the cache contents of layer 0.
 
 The oracle goes through the model LAYER by layer (LlamaRef.generate_forced_layer_major: every fed token is known, the
@@ -21,7 +22,7 @@ pytestmark = pytest.mark.gpu
 # Tolerance = ~2.5-3 x the measured maximum (logits of std ~1.3).  Measured on MI355X, round 4: fp16 int4 7B x 32 layers
 # 0.037 (one layer at B = 32: 0.0097); bf16 1.1B x 22 layers 0.103 (two layers: 0.047).
 DEPTH_CASES = {
-    "cfg3-llama7b-gptq-32layers": (LLAMA_7B, 32, "gptq", torch.float16, [96, 64, 33, 100], 3, 0.10),
+    "cfg3-llama7b-gptq-32layers": (LLAMA_7B, 32, "gptq", torch.float16, [48, 64, 33, 17], 3, 0.10),
     "cfg2-tinyllama-bf16-22layers": (TINYLLAMA, 22, None, torch.bfloat16, [96, 64, 33, 100], 3, 0.30),
 }
 MAX_TIE_ROWS_PER_STEP = 2  # rows per step the oracle itself decides by less than 2 x tolerance (4 rows here: normally 0)

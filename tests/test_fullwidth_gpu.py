@@ -59,19 +59,38 @@ def _prompts(B, L, V, seed):
     return [rng.integers(3, V, size=L).tolist() for _ in range(B)]
 
 
-def _make(family, kw, layers, quantize, dtype, seed):
-    """(product config, oracle config, seeded CPU tensors).  One recipe for both sides: tgis_amd's synthetic
-    generator (SURVEY §8d weights) — the oracle reads the very same tensors."""
-    from tgis_amd.inference_engine.synthetic import BigCodeConfig, bigcode_tensors, llama_tensors
+def _config(family, kw, layers):
+    from tgis_amd.inference_engine.synthetic import BigCodeConfig
     from tgis_amd.models.custom_modeling.flash_llama_modeling import LlamaConfig
 
     if family == "llama":
-        cfg = LlamaConfig(num_hidden_layers=layers, max_position_embeddings=4096, **kw)
+        return LlamaConfig(num_hidden_layers=layers, max_position_embeddings=4096, **kw)
+    return BigCodeConfig(num_hidden_layers=layers, **kw)
+
+
+def _make(family, kw, layers, quantize, dtype, seed):
+    """(product config, oracle config, seeded CPU tensors).  One recipe for both sides: tgis_amd's synthetic
+    generator (SURVEY §8d weights) — the oracle reads the very same tensors."""
+    from tgis_amd.inference_engine.synthetic import bigcode_tensors, llama_tensors
+
+    cfg = _config(family, kw, layers)
+    if family == "llama":
         tensors = llama_tensors(cfg, quantize, seed=seed, device="cpu", dtype=dtype)
     else:
-        cfg = BigCodeConfig(num_hidden_layers=layers, **kw)
         tensors = bigcode_tensors(cfg, seed=seed, device="cpu", dtype=dtype)
     return cfg, tensors
+
+
+def _shared_tensor_file(tensors):
+    """The seeded full-width tensors, built ONCE by the test process and mapped by every rank (round 5: each of the eight
+    ranks used to generate and pack the same matrices; the GPU suite has a 1200 s budget on the driver's box)."""
+    import tempfile
+
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    fd, path = tempfile.mkstemp(prefix="tgis_fullwidth_", suffix=".pt", dir=base)
+    os.close(fd)
+    torch.save(tensors, path)
+    return path
 
 
 def _oracle(family, cfg, tensors, quantize):
@@ -208,7 +227,7 @@ def _free_port():
     return p
 
 
-def _tp_worker(rank, world, port, ret, case="cfg4"):
+def _tp_worker(rank, world, port, ret, case="cfg4", tensor_path=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       TGIS_DIST_BACKEND="gloo", TGIS_ALLOW_SHARED_GPU="1", TGIS_DIST_TIMEOUT_S="900")
     import sys
@@ -218,14 +237,18 @@ def _tp_worker(rank, world, port, ret, case="cfg4"):
         if p not in sys.path:
             sys.path.insert(0, p)
     from tests.fixture_utils import FixtureTokenizer
-    from tests.test_fullwidth_gpu import TP_CASES, _make, _prompts, _run_product
+    from tests.test_fullwidth_gpu import TP_CASES, _config, _make, _prompts, _run_product
     from tgis_amd.inference_engine.synthetic import InferenceEngine
     from tgis_amd.models.flash_causal_lm import FlashCausalLM
     from tgis_amd.utils.kv_cache import PagedKVCache
 
     torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     family, (name, kw, layers, quantize, dtype, B, L, steps, tol) = TP_CASES[case]
-    cfg, tensors = _make(family, kw, layers, quantize, dtype, seed=4321)
+    if tensor_path is not None:
+        cfg = _config(family, kw, layers)
+        tensors = torch.load(tensor_path, mmap=True, weights_only=True)
+    else:
+        cfg, tensors = _make(family, kw, layers, quantize, dtype, seed=4321)
     prompts = _prompts(B, L, cfg.vocab_size, seed=99)
     tok = FixtureTokenizer(cfg.vocab_size)
     eng = InferenceEngine(tensors, cfg, dtype, quantize, tokenizer=tok)
@@ -251,14 +274,18 @@ def test_cfg4_tp8_shard_shapes_match_oracle(gpu_device):
     mgr = mp.get_context("spawn").Manager()  # never fork a process that has run gRPC (or CUDA) threads
     ret = mgr.dict()
     t0 = time.time()
-    mp.spawn(_tp_worker, args=(8, _free_port(), ret), nprocs=8, join=True)
+    cfg, tensors = _make("llama", kw, layers, quantize, dtype, seed=4321)
+    path = _shared_tensor_file(tensors)
+    try:
+        mp.spawn(_tp_worker, args=(8, _free_port(), ret, "cfg4", path), nprocs=8, join=True)
+    finally:
+        os.unlink(path)
     t1 = time.time()
     got = ret["got"]
     assert ret["shapes"] == [(1024, 8192), (3584, 8192), (8192, 1280), (8192, 7168)], ret["shapes"]
     assert ret["heads"] == (8, 1)
     for r in range(1, 8):
         assert ret[f"ids{r}"] == [g[0] for g in got], "ranks must stay in lock-step without a broadcast"
-    cfg, tensors = _make("llama", kw, layers, quantize, dtype, seed=4321)
     prompts = _prompts(B, L, cfg.vocab_size, seed=99)
     ref = LlamaRef(cfg, tensors, quantize=quantize, groupsize=128)
     want = ref.generate_greedy(prompts, steps, forced=[g[0] for g in got])
@@ -274,13 +301,17 @@ def test_cfg5_tp4_shard_shapes_match_oracle(gpu_device):
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
     t0 = time.time()
-    mp.spawn(_tp_worker, args=(4, _free_port(), ret, "cfg5"), nprocs=4, join=True)
+    cfg, tensors = _make(family, kw, layers, quantize, dtype, seed=4321)
+    path = _shared_tensor_file(tensors)
+    try:
+        mp.spawn(_tp_worker, args=(4, _free_port(), ret, "cfg5", path), nprocs=4, join=True)
+    finally:
+        os.unlink(path)
     t1 = time.time()
     got = ret["got"]
     assert ret["heads"] == (12, 1), ret["heads"]
     for r in range(1, 4):
         assert ret[f"ids{r}"] == [g[0] for g in got], "ranks must stay in lock-step without a broadcast"
-    cfg, tensors = _make(family, kw, layers, quantize, dtype, seed=4321)
     prompts = _prompts(B, L, cfg.vocab_size, seed=99)
     ref = SantacoderRef(cfg, tensors)
     want = ref.generate_greedy(prompts, steps, forced=[g[0] for g in got])

@@ -124,6 +124,8 @@ static int launch_dense(const DenseArgs& a, const DensePlan& pl, int act, int64_
              : act == 2 ? launch_dense_variant<T, T_, W_, 2>(pl.MR, grid, lds, st, a)                                           \
              : act == 1 ? launch_dense_variant<T, T_, W_, 1>(pl.MR, grid, lds, st, a)                                           \
                         : launch_dense_variant<T, T_, W_, 0>(pl.MR, grid, lds, st, a)
+    // one tile per k-part group: the fused qkv + rotary launch of a narrow projection (TinyLlama: 80 tiles, unsplit)
+    if (pl.TN == 1 && pl.WK == 4 && act == 3) rc = launch_dense_variant<T, 1, 4, 3>(pl.MR, grid, lds, st, a);
     TGIS_DENSE_CASE(2, 2);
     TGIS_DENSE_CASE(2, 4);
     TGIS_DENSE_CASE(3, 4);
@@ -246,13 +248,22 @@ extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared,
 }
 
 // ---- qkv projection with the rotary embedding and the cache write in its epilogue (dense weights) ---------------------
+// The unsplit plan of the fused qkv + rotary launch: plan_dense's SiLU plan, with ONE tile per k-part group where two would
+// leave fewer than 128 blocks (round 5: TinyLlama's 80 tiles ran as 40 blocks of 262 KB each — one CU takes in ~50 GB/s).
+static DensePlan plan_dense_rope(int64_t K, int64_t N, int64_t M) {
+    DensePlan pl = plan_dense(K, N, M, 2);
+    const int64_t tiles = cdiv64(N, 32);
+    if (M <= 32 && pl.WK == 4 && cdiv64(tiles, pl.TN) < 128) pl.TN = 1;
+    return pl;
+}
+
 extern "C" int tgis_dense_rope_ok(int64_t M, int64_t K, int64_t N, int64_t D) {
     if (M < 1 || M > 64 || D < 32 || D % 32 || N <= 0 || N % D || K <= 0 || K % 8) return 0;
-    // as tgis_gptq_rope_ok: the unsplit plan must still cover the chip
-    const DensePlan pl = plan_dense(K, N, M, 2);
+    // as tgis_gptq_rope_ok: the unsplit plan must still cover the chip — from 64 blocks on when they are one-tile blocks
+    const DensePlan pl = plan_dense_rope(K, N, M);
     const int64_t blocks = cdiv64(cdiv64(N, 32), pl.TN);
     static const int64_t min_blocks = getenv("TGIS_ROPE_MIN_BLOCKS") ? atoll(getenv("TGIS_ROPE_MIN_BLOCKS")) : 128;
-    return blocks >= min_blocks ? 1 : 0;
+    return blocks >= (pl.TN == 1 ? std::min<int64_t>(min_blocks, 64) : min_blocks) ? 1 : 0;
 }
 
 extern "C" int tgis_dense_gemm_rope(const void* x, int64_t ldx, const void* prepared, const void* bias,
@@ -267,7 +278,7 @@ extern "C" int tgis_dense_gemm_rope(const void* x, int64_t ldx, const void* prep
     TGIS_CHECK_ARG(H >= 1 && Hkv >= 1 && (H + 2 * Hkv) * D == N && ldq >= H * D,
                    "tgis_dense_gemm_rope: N must be (H + 2 Hkv) * D and q rows must hold H * D elements");
     hipStream_t st = (hipStream_t)stream;
-    DensePlan pl = plan_dense(K, N, M, 2);  // as the SiLU epilogue: the whole k range in one block (S == 1)
+    DensePlan pl = plan_dense_rope(K, N, M);  // as the SiLU epilogue: the whole k range in one block (S == 1)
     TgisTimedScope timed(TGIS_OP_DENSE_GEMM, st);
     DenseArgs a;
     dense_fill(a, x, ldx, prepared, bias, q_out, ldq, M, K, N, 0, nullptr, 0, pl);
