@@ -25,6 +25,13 @@
 #include "attention_args.h"
 #include "kv_layout.h"
 
+// tools/floor/attn_unit.hip compiles this unit with per-wave s_memtime stamps (ATTN_STAMP*); the library does not.
+#ifndef ATTN_STAMP
+#define ATTN_STAMP_DECL
+#define ATTN_STAMP(i)
+#define ATTN_STAMP_FLUSH
+#endif
+
 namespace {
 
 
@@ -43,6 +50,8 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
         const void* l2 = a.counters;
         asm volatile("" ::"s"(l0), "s"(l1), "s"(l2));
     }
+    ATTN_STAMP_DECL
+    ATTN_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: the block-table reads become scalar loads
     const int col = lane & 15, c = lane >> 4;
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     const int t0 = qt * a.TQ;
     if (t0 >= q_len) return;
     const int ctx = a.ctx_lens[b];
-    const int tq = col / a.Gp, g = col % a.Gp;
+    const int tq = col >> a.Gp_shift, g = col & (a.Gp - 1);
     bool col_valid[CH];
     int kmax[CH];  // this column may attend to key positions < kmax
 #pragma unroll
@@ -81,6 +90,12 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     const int pages = (kend + 31) >> 5;
     const int pps = (pages + a.NS - 1) / a.NS;
     const int pbeg = split * pps, pend = min(pages, pbeg + pps);
+    ATTN_STAMP(1);  // (the sequence's lengths are in: the stamp macro waits for scalar loads)
+    // The first fully visible page's table entry is asked for HERE — as soon as the lengths are in, in front of the q loads and
+    // of the partly visible pages: behind them it was a scalar round trip with nothing of this wave in flight (round 5 timeline,
+    // profiles/r05_attn_timeline.log: multi-chunk blocks had their first entry 4.8 k ticks after entry, 3.5 k after the lengths).
+    const int32_t* btrow = a.bt + (int64_t)b * a.max_pages;
+    const int pg_first = (pbeg + w < pend) ? btrow[pbeg + w] : 0;
 
     // Q^T fragments (B operand): lane supplies Q[col][ks*32 + c*8 .. +8]
     V8 qf[CH][KS];
@@ -183,7 +198,6 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
         lsum[ch] = 0.f;
     }
 
-    const int32_t* btrow = a.bt + (int64_t)b * a.max_pages;
     // one page of K (two 16-token halves x KS k-steps) and V^T (NB 16-row blocks): 16 KiB per wave at D = 128
     auto load_page = [&](const int pg, V8 (&kf)[2][KS], V8 (&vf)[NB]) {
         const T* kb = reinterpret_cast<const T*>(a.kpool) + ((int64_t)pg * a.Hkv + hk) * (32 * D) + lane * 8;
@@ -254,13 +268,12 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) o[ch][nb] = mfma16(vf[nb], pf, o[ch][nb]);
         }
+        ATTN_STAMP(3);  // (kept once: the wave's first page applied)
     };
     // pages below kfull are visible in full to every column of the tile (the tile's first token sees kfull keys)
     const int kfull = ctx - q_len + t0 + 1;
     int p = pbeg + w;
-    // the first fully visible page's table entry is asked for HERE, in front of the partly visible pages: behind them it was
-    // a scalar round trip with nothing of this wave in flight
-    const int pg_first = (p < pend) ? btrow[p] : 0;
+    ATTN_STAMP(2);  // q requested, first table entry in
     // The partly visible pages of this wave (decode: the sequence's last page) go FIRST (round 4): the softmax is order-
     // independent, and their masked body is a second copy of the page code that each wave runs once — at the end of the
     // launch its instruction fetch and its un-overlapped load were part of every block's tail (ctx 1023 vs 1024: +2.6 us
@@ -313,6 +326,7 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
         pg = pg_next;
     }
 
+    ATTN_STAMP(4);  // pages done
     // ---- combine the 4 waves through LDS ----------------------------------------------------------
     float* so = reinterpret_cast<float*>(smem);          // [CH][NW][D][16]
     float* sml = so + CH * NW * D * 16;                  // [CH][NW][2][16]
@@ -324,13 +338,16 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) so[((ch * NW + w) * D + nb * 16 + c * 4 + r) * 16 + col] = o[ch][nb][r];
+            // (row d = nb 16 + c 4 + r sits at nb 16 + r 4 + c: the four 16-lane groups of a store then hit four different
+            // groups of 16 banks instead of the same one — round 5: the [d][16] order was a 4-way conflict on every access)
+            for (int r = 0; r < 4; ++r) so[((ch * NW + w) * D + nb * 16 + r * 4 + c) * 16 + col] = o[ch][nb][r];
         if (c == 0) {
             sml[((ch * NW + w) * 2 + 0) * 16 + col] = m[ch];
             sml[((ch * NW + w) * 2 + 1) * 16 + col] = ls;
         }
     }
     __syncthreads();
+    ATTN_STAMP(5);  // every wave's O and statistics in LDS
     const int grp = blockIdx.x + gridDim.x * (by + gridDim.y * b);  // the NS blocks that share their columns
     __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.ws_o, 0, 0x7FFFFFFF, 0x00020000);
     __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.ws_ml, 0, 0x7FFFFFFF, 0x00020000);
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     for (int item = tid; item < CH * 16 * (D / 8); item += 64 * NW) {
         const int j = item & 15, dc = (item >> 4) % (D / 8), ch = item / (16 * (D / 8));
         const int hc = hc0 + ch;
-        const int tqj = j / a.Gp, gj = j % a.Gp;
+        const int tqj = j >> a.Gp_shift, gj = j & (a.Gp - 1);
         if (!(gj < a.Gc && hc * 16 + gj < a.G && t0 + tqj < q_len)) continue;
         const float* soc = so + ch * NW * D * 16;
         const float* smc = sml + ch * NW * 2 * 16;
@@ -354,7 +371,10 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
             float f = exp2f(mw[k] - mstar);
             l += smc[(k * 2 + 1) * 16 + j] * f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += soc[(k * D + dc * 8 + e) * 16 + j] * f;
+            for (int e = 0; e < 8; ++e) {
+                const int d = dc * 8 + e;
+                acc[e] += soc[(k * D + ((d & ~15) | ((d & 3) << 2) | ((d >> 2) & 3))) * 16 + j] * f;
+            }
         }
         const int64_t tokidx = q0 + t0 + tqj;
         const int headj = hk * a.G + hc * 16 + gj;
@@ -387,6 +407,8 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
             }
         }
     }
+    ATTN_STAMP(6);  // output or split record stored
+    ATTN_STAMP_FLUSH
     if (a.NS == 1 || !a.counters) return;
 
     // ---- the last of the group's NS blocks to get here merges the NS records (what attn_combine_kernel does in a
@@ -418,7 +440,7 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
         for (int it = 0; it < IB; ++it) {
             const int item = tid + (it0 + it) * THREADS;
             const int j = item & 15, dc = (item >> 4) % (D / 8), ch = item / (16 * (D / 8));
-            const int tqj = j / a.Gp, gj = j % a.Gp;
+            const int tqj = j >> a.Gp_shift, gj = j & (a.Gp - 1);
             ok[it] = item < ITEMS && gj < a.Gc && (hc0 + ch) * 16 + gj < a.G && t0 + tqj < q_len;
             rec0[it] = ok[it] ? (((int64_t)grp * CH + ch) * 16 + j) * a.NS : 0;  // (clamped: the loads stay in bounds)
             dcs[it] = dc;
@@ -470,7 +492,7 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
             if (!ok[it]) continue;
             const int item = tid + (it0 + it) * THREADS;
             const int j = item & 15, ch = item / (16 * (D / 8));
-            const int tqj = j / a.Gp, gj = j % a.Gp;
+            const int tqj = j >> a.Gp_shift, gj = j & (a.Gp - 1);
             const float inv = lrun[it] > 0.f ? 1.f / lrun[it] : 0.f;
             V8 ov;
 #pragma unroll
@@ -808,6 +830,8 @@ static int attn_paged_impl(const void* q, int64_t ld_q, const void* k_pool, cons
     a.G = g.G;
     a.Gc = g.Gc;
     a.Gp = g.Gp;
+    a.Gp_shift = 0;
+    while ((1 << a.Gp_shift) < g.Gp) ++a.Gp_shift;
     a.TQ = g.TQ;
     a.HC = g.HC;
     const int ch = chunks_per_block(g.HC, max_q_len);

@@ -14,6 +14,7 @@ struct AttnArgs {
     void* out;
     int out_frag;  // 1: out is [<= 32 tokens, H * D] in 32-row fragment order (xf_off in common.h), else row-major
     int H, Hkv, G, Gc, Gp, TQ, HC, NS;
+    int Gp_shift;  // Gp is a power of two: column -> (q token, head of the group) by shift and mask, not by division
     int HCB;  // decode kernel: blocks per kv head along the 16-head chunks (HC / chunks per block)
     int xcd_remap;  // decode kernel, HCB > 1: the chunk blocks of a (sequence, split, kv head) group run on one XCD
     float scale_log2;

@@ -38,14 +38,14 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs a) {
     const int t0 = qt * TQB;
     if (t0 >= q_len) return;
     const int ctx = a.ctx_lens[b];
-    const int g = col % a.Gp;
+    const int g = col & (a.Gp - 1);
     const int head = hk * a.G + hc * 16 + g;
     int tq[CG], kmax[CG];
     bool col_valid[CG];
     int wave_kmax = 0, wave_kmin = 0x7fffffff;
 #pragma unroll
     for (int cg = 0; cg < CG; ++cg) {
-        tq[cg] = ((w * CG + cg) * 16 + col) / a.Gp;
+        tq[cg] = ((w * CG + cg) * 16 + col) >> a.Gp_shift;
         col_valid[cg] = (g < a.Gc) && (hc * 16 + g < a.G) && (t0 + tq[cg] < q_len);
         kmax[cg] = col_valid[cg] ? (ctx - q_len + t0 + tq[cg] + 1) : 0;  // this column attends to positions < kmax
         wave_kmax = max(wave_kmax, kmax[cg]);
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slice: no barrier, only the wave's own LDS order
         for (int item = lane; item < 16 * (D / 8); item += 64) {
             const int j = item & 15, dc = item >> 4;
-            const int tqj = ((w * CG + cg) * 16 + j) / a.Gp, gj = j % a.Gp;
+            const int tqj = ((w * CG + cg) * 16 + j) >> a.Gp_shift, gj = j & (a.Gp - 1);
             if (!(gj < a.Gc && hc * 16 + gj < a.G && t0 + tqj < q_len)) continue;
             V8 ov;
 #pragma unroll
