@@ -1,3 +1,6 @@
+// EXPERIMENT (round 5; experiments/README.md): measured ON PAR with the product's streaming dense kernel, so it is not part
+// of libtgis_hip.so.  The full wiring (entry points, ctypes binding, FastLinear, tests) is commit 1e13390.
+//
 // The dense (f16 / bf16 weights) decode GEMM for batches of up to 32 rows whose activation arrives in MFMA-fragment order
 // (round 5) — the structure of gptq_wide_body.h without the dequantisation.
 //

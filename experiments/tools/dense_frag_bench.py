@@ -1,5 +1,5 @@
 """Round 5: the dense decode GEMM on a fragment-order operand (csrc/dense_wide_body.h) against the row-major streaming kernel
-(csrc/dense_gemm_body.h), GPU time per launch from a captured graph over rotating weights.  GPU box only.
+(csrc/dense_gemm_body.h), GPU time per launch from a captured graph over rotating weights.  GPU box only; runs on the tree of commit 1e13390 (the round-5 commit that had the kernel wired into the library).
     python tools/dense_frag_bench.py"""
 import os
 import sys

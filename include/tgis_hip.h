@@ -99,8 +99,7 @@ int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
  * [M <= 64, K] f16 activation (K % 64 == 0; the buffer holds ceil(M / 32) * 32 * K elements) is stored in the order the MFMA
  * reads it — [row block m/32][k64-step][i = k/8 % 4][lane = 32 (k/32 % 2) + m % 32][k % 8], i.e. element (m, k) at
  * (m/32) * 32 K + ((k/64 * 4 + k/8 % 4) * 64 + 32 (k/32 % 2) + m % 32) * 8 + k % 8 — instead of row-major.  Producers that can write it:
- * tgis_rmsnorm_residual[_partial] (ldy), tgis_attn_paged (ld_out), tgis_gptq_gemm_f16 with act = 2 (ldo), tgis_dense_gemm (ldo;
- * f16 or bf16 there).  Consumers:
+ * tgis_rmsnorm_residual[_partial] (ldy), tgis_attn_paged (ld_out), tgis_gptq_gemm_f16 with act = 2 (ldo).  Consumers:
  * tgis_gptq_gemm_f16, tgis_gptq_gemm_f16_partial, tgis_gptq_gemm_rope_f16 (ldx), which then run the kernel of
  * csrc/gptq_wide_body.h: each k64-step of the activation is four contiguous KiB straight into the A operand, no LDS staging
  * (7B shapes, 32 rows: qkv + rope 16.9 -> 12 us, o 6.0 -> 5.3, gate_up 16.8 -> 14.4, down 10.5 -> 9.2).  Same arithmetic as
@@ -179,15 +178,6 @@ int64_t tgis_dense_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
 int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared, const void* bias, void* out,
                     int64_t ldo, int64_t M, int64_t K, int64_t N, int dtype, int out_f32, int act,
                     void* workspace, int64_t workspace_bytes, void* stream);
-/* Round 5: the dense decode GEMMs take their operand in fragment order as well (ldx = TGIS_LD_FRAGMENTS on tgis_dense_gemm,
- * tgis_dense_gemm_partial and tgis_dense_gemm_rope: 1 <= M <= 32, K % 64 == 0, N % 32 == 0, act 0 / 2 / 4 / 5) and then run the
- * kernel of csrc/dense_wide_body.h — the structure of the int4 fragment-order kernel without the dequantisation: the A operand
- * of a k64-step is four contiguous KiB straight from L2, a wave owns 1 - 4 column tiles over its own k range, no LDS staging
- * of the activation.  The model-dtype output of tgis_dense_gemm may leave in fragment order too (ldo = TGIS_LD_FRAGMENTS;
- * act 2: N / 2 % 64 == 0, else N % 64 == 0) for the dense GEMM behind it.  Same arithmetic as the row-major launch; only the
- * summation order over k differs.  tgis_dense_fragments_ok: 1 if the GEMM (act 0 / 4 / 5, 2 = the gate | up image, 3 = the rope
- * image of tgis_dense_gemm_rope) takes such an activation (act != 0 additionally needs >= 64 workgroups in the unsplit plan). */
-int tgis_dense_fragments_ok(int64_t M, int64_t K, int64_t N, int act);
 /* Deferred split-K, as tgis_gptq_gemm_f16_partial: the fp32 partial sums [ceil(M/32)][num_slabs][32][slab_ld] are
  * left for the consumer kernel (tgis_rmsnorm_residual_partial / tgis_rope_kv_write_partial), which adds the bias. */
 int64_t tgis_dense_gemm_partial_bytes(int64_t M, int64_t K, int64_t N);

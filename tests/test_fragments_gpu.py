@@ -204,95 +204,3 @@ def test_decode_attention_writes_the_same_bits_in_fragment_order(nat, gpu_device
         o1 = nat.FragAct.empty(B, H * D, gpu_device)
         nat.attn_paged(q, H * D, kp, vp, btd, ctxd, cuq, o1, B, H, Hkv, D, 1, max(lens), D ** -0.5, ns, ws)
         assert torch.equal(o1.to_rows(), o0), f"{ns} splits"
-
-
-# ---- round 5: the dense (f16 / bf16) decode GEMMs read fragment-order operands too (csrc/dense_wide_body.h) --------------------
-DENSE_SHAPES = [
-    (16, 2048, 2560),    # TinyLlama qkv
-    (16, 2048, 2048),    # o_proj: four k splits of one step per wave
-    (16, 5632, 2048),    # down_proj: 88 k64-steps, ragged shares
-    (32, 6144, 6400),    # Starcoder c_attn
-    (32, 6144, 6144),
-    (7, 128, 96),        # three tiles, two steps: six of the eight waves have nothing to do
-    (1, 64, 32),
-    (32, 4096, 32000),   # lm_head: four tiles per wave
-]
-
-
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,K,N", DENSE_SHAPES)
-def test_dense_fragment_gemm_matches_x_wT_and_the_row_major_launch(nat, gpu_device, dtype, M, K, N):
-    g = torch.Generator().manual_seed(M + K + N)
-    x = (torch.randn(M, K, generator=g) * 0.5).to(dtype)
-    wt = (torch.randn(N, K, generator=g) * 0.03).to(dtype)
-    bias = (torch.randn(N, generator=g) * 0.1).to(dtype)
-    want = x.float() @ wt.float().t() + bias.float()
-    w = nat.DenseWeight(wt.to(gpu_device))
-    assert nat.dense_fragments_ok(M, w, 0)
-    ws = nat.Workspace(w.workspace_bytes(M), gpu_device)
-    xd, bd = x.to(gpu_device), bias.to(gpu_device)
-    xf = nat.FragAct.from_rows(xd)
-    if M % 32:  # rows past M must not matter
-        xf.buf.view(1, -1, 2, 32, 8)[0][:, :, M % 32:].fill_(float("nan"))
-    got = nat.dense_gemm(xf, w, ws, bias=bd)
-    row = nat.dense_gemm(xd, w, ws, bias=bd)
-    eps = 2.0 ** -11 if dtype == torch.float16 else 2.0 ** -8
-    scale = float(want.abs().max())
-    assert float((got.float().cpu() - want).abs().max()) <= 2 * eps * scale + 1e-3
-    assert float((got.float() - row.float()).abs().max()) <= 2 * eps * scale + 1e-3, "fragment and row-major launches disagree"
-    assert torch.equal(got, nat.dense_gemm(xf, w, ws, bias=bd)), "not deterministic"
-    # fp32 output (logits) and the deferred reduce
-    got32 = nat.dense_gemm(xf, w, ws, bias=bd, out_f32=True)
-    assert float((got32.cpu() - want).abs().max()) <= 1e-3 * scale + 1e-3
-    p = nat.dense_gemm_partial(xf, w, bias=bd)
-    sl = p.slabs[:p.S * 32 * p.ld].view(p.S, 32, p.ld).sum(0)[:M, :N] + bd.float()
-    assert float((sl.cpu() - want).abs().max()) <= 1e-3 * scale + 1e-3
-    if N % 64 == 0:  # the output in fragment order (always an unsplit plan: another summation order than a split `got`)
-        of = nat.dense_gemm(xf, w, ws, bias=bd, out_frag=True)
-        assert isinstance(of, nat.FragAct)
-        assert float((of.to_rows().float() - got.float()).abs().max()) <= 2 * eps * scale + 1e-3
-
-
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,K,I", [(16, 2048, 5632), (32, 4096, 11008), (5, 256, 192)])
-def test_dense_fragment_gemm_silu_epilogue(nat, gpu_device, dtype, M, K, I):
-    g = torch.Generator().manual_seed(I)
-    x = (torch.randn(M, K, generator=g) * 0.5).to(dtype).to(gpu_device)
-    wt = (torch.randn(2 * I, K, generator=g) * 0.03).to(dtype).to(gpu_device)
-    w = nat.DenseWeight(wt, gate_up=True)
-    ws = nat.Workspace(w.workspace_bytes(M), gpu_device)
-    xf = nat.FragAct.from_rows(x)
-    a_row = nat.dense_gemm(xf, w, ws, act=2)
-    base = nat.dense_gemm(x, w, ws, act=2)
-    lin = (x.float().cpu() @ wt.float().cpu().t()).to(dtype)
-    want = ops_ref.silu_mul(lin.view(M, 2 * I), I)
-    scale = float(want.float().abs().max())
-    eps = 2.0 ** -11 if dtype == torch.float16 else 2.0 ** -8
-    assert float((a_row.float().cpu() - want.float()).abs().max()) <= 8 * eps * scale + 1e-3
-    assert float((a_row.float() - base.float()).abs().max()) <= 8 * eps * scale + 1e-3
-    if I % 64 == 0:
-        a_frag = nat.dense_gemm(xf, w, ws, act=2, out_frag=True)
-        assert torch.equal(a_frag.to_rows(), a_row)
-
-
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("H,Hkv,D,K,B", [(32, 4, 64, 2048, 16), (8, 8, 128, 1024, 7), (4, 1, 128, 512, 32)])
-def test_dense_fragment_gemm_rope_epilogue(nat, gpu_device, dtype, H, Hkv, D, K, B):
-    N = (H + 2 * Hkv) * D
-    g = torch.Generator().manual_seed(H * D + B)
-    x = (torch.randn(B, K, generator=g) * 0.5).to(dtype).to(gpu_device)
-    wt = (torch.randn(N, K, generator=g) * 0.03).to(dtype).to(gpu_device)
-    wr = nat.DenseWeight(wt, rope=(D, H + Hkv))
-    cos, sin = ops_ref.rope_tables(D, 10000.0, 80, dtype)
-    cos, sin = cos.to(gpu_device), sin.to(gpu_device)
-    pos = torch.randint(0, 80, (B,), generator=g).int().to(gpu_device)
-    slots = torch.randperm(8 * 32, generator=g)[:B].int().to(gpu_device)
-    pools = [torch.zeros((8, Hkv, 32 * D), dtype=dtype, device=gpu_device) for _ in range(4)]
-    q0 = nat.dense_gemm_rope(x, wr, None, cos, sin, pos, slots, pools[0], pools[1], H, Hkv, D)
-    q1 = nat.dense_gemm_rope(nat.FragAct.from_rows(x), wr, None, cos, sin, pos, slots, pools[2], pools[3], H, Hkv, D)
-    scale = float((x.float() @ wt.float().t()).abs().max())
-    eps = 2.0 ** -11 if dtype == torch.float16 else 2.0 ** -8
-    for name, a, b in (("q", q0[:, :H * D], q1[:, :H * D]), ("k pages", pools[0], pools[2]), ("v pages", pools[1], pools[3])):
-        diff = (a.float() - b.float()).abs()
-        assert float(diff.max()) <= 4 * eps * scale, f"{name}: more than a rounding apart"
-    assert pools[2].abs().sum() > 0 and pools[3].abs().sum() > 0

@@ -9,7 +9,6 @@
 #include <type_traits>
 #include "common.h"
 #include "dense_gemm_body.h"
-#include "dense_wide_body.h"
 
 namespace {
 
@@ -148,51 +147,6 @@ static int launch_dense(const DenseArgs& a, const DensePlan& pl, int act, int64_
     return TGIS_OK;
 }
 
-// ---- decode batches of up to 32 rows whose activation is in fragment order (dense_wide_body.h, round 5) ------------------
-template <typename T, int CT, int ACT, bool OUTF>
-__global__ __launch_bounds__(64 * dense::DWIDE_WK) void dense_wide_kernel(DenseArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    dense::dense_wide_unit<T, CT, ACT, OUTF>(a, smem);
-}
-
-template <typename T, int CT, int ACT, bool OUTF>
-static int launch_dwide_one(dim3 grid, hipStream_t st, const DenseArgs& a) {
-    const size_t lds = dense::dwide_lds_bytes(CT);
-    static bool attr = false;
-    if (!attr && lds > 48 * 1024) {
-        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)dense_wide_kernel<T, CT, ACT, OUTF>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
-    hipLaunchKernelGGL((dense_wide_kernel<T, CT, ACT, OUTF>), grid, dim3(64 * dense::DWIDE_WK), lds, st, a);
-    return TGIS_OK;
-}
-
-// act 0 (plain / bias / GELU / fp32 / slabs), 2 (SiLU * up), 3 (rotary + cache write); outf: the act 0 / 2 output in fragment order
-template <typename T>
-static int launch_dwide(const DenseArgs& a, const dense::DWidePlan& pl, int act, bool outf, hipStream_t st) {
-    dim3 grid((unsigned)cdiv64(a.NT, pl.CT), (unsigned)pl.S);
-    int rc = TGIS_EINVAL;
-#define TGIS_DWIDE(CT_)                                                                            \
-    if (pl.CT == CT_)                                                                              \
-        rc = act == 3   ? launch_dwide_one<T, CT_, 3, false>(grid, st, a)                          \
-             : act == 2 ? (outf ? launch_dwide_one<T, CT_, 2, true>(grid, st, a)                   \
-                                : launch_dwide_one<T, CT_, 2, false>(grid, st, a))                 \
-                        : (outf ? launch_dwide_one<T, CT_, 0, true>(grid, st, a)                   \
-                                : launch_dwide_one<T, CT_, 0, false>(grid, st, a))
-    TGIS_DWIDE(1);
-    TGIS_DWIDE(2);
-    TGIS_DWIDE(3);
-    TGIS_DWIDE(4);
-#undef TGIS_DWIDE
-    if (rc != TGIS_OK) {
-        tgis_set_error("tgis_dense_gemm: no fragment-order kernel for CT=%d", pl.CT);
-        return rc;
-    }
-    TGIS_CHECK_LAUNCH();
-    return TGIS_OK;
-}
-
 }  // namespace
 
 extern "C" int64_t tgis_dense_prepared_bytes(int64_t N, int64_t K) {
@@ -227,9 +181,7 @@ extern "C" int tgis_dense_prepare(const void* w, int64_t N, int64_t K, int dtype
 
 extern "C" int64_t tgis_dense_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N) {
     DensePlan pl = plan_dense(K, N, M);  // (act 2 never splits: this bound covers it)
-    int64_t S = pl.S;
-    if (dense::dwide_serves(M, K, N)) S = std::max<int64_t>(S, dense::plan_dwide(K, N, false).S);
-    return 4096 + (S > 1 ? dense_slab_bytes(M, N, S) : 0);
+    return 4096 + (pl.S > 1 ? dense_slab_bytes(M, N, pl.S) : 0);
 }
 
 static int dense_check(const void* x, int64_t ldx, const void* prepared, int64_t M, int64_t K, int64_t N, int dtype,
@@ -240,12 +192,6 @@ static int dense_check(const void* x, int64_t ldx, const void* prepared, int64_t
     TGIS_CHECK_ARG(dtype == TGIS_F16 || dtype == TGIS_BF16, "tgis_dense_gemm: bad dtype");
     TGIS_CHECK_ARG((act >= 0 && act <= 2) || act == 4 || act == 5, "tgis_dense_gemm: act must be 0, 1, 2, 4 or 5");
     TGIS_CHECK_ARG(act != 2 || N % 32 == 0, "tgis_dense_gemm: act 2 needs a gate|up image (N / 2 a multiple of 16)");
-    if (ldx == TGIS_LD_FRAGMENTS) {
-        TGIS_CHECK_ARG(((uintptr_t)x % 16) == 0 && dense::dwide_serves(M, K, N) && act != 1,
-                       "tgis_dense_gemm: an activation in fragment order needs 1 <= M <= 32, K %% 64 == 0, N %% 32 == 0 and no "
-                       "act 1 (M=%ld K=%ld N=%ld act=%d)", (long)M, (long)K, (long)N, act);
-        return TGIS_OK;
-    }
     TGIS_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, "tgis_dense_gemm: x rows must be 16-byte aligned");
     return TGIS_OK;
 }
@@ -287,37 +233,6 @@ extern "C" int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared,
     hipStream_t st = (hipStream_t)stream;
     const int gelu = act == 4 ? 1 : act == 5 ? 2 : 0;  // GELU of the finished sum: epilogue (unsplit) or split-K reduce
     if (gelu) act = 0;
-    if (ldx == TGIS_LD_FRAGMENTS) {
-        // the fragment-order kernel: this entry point returns a FINISHED output, so a split plan costs the reduce launch on top
-        // — taken only where the unsplit plan would leave fewer than 128 blocks; a fragment-order output is always unsplit
-        const bool outf = ldo == TGIS_LD_FRAGMENTS;
-        TGIS_CHECK_ARG(!outf || (!out_f32 && (act == 2 ? (N / 2) % 64 == 0 : N % 64 == 0)),
-                       "tgis_dense_gemm: a fragment-order output is the model dtype with a multiple of 64 columns");
-        TGIS_CHECK_ARG(act != 2 || !out_f32, "tgis_dense_gemm: act 2 writes the model dtype");
-        TGIS_CHECK_ARG(!gelu || !out_f32, "tgis_dense_gemm: act 4 / 5 (GELU) write the model dtype");
-        dense::DWidePlan wp = dense::plan_dwide(K, N, act == 2 || outf);
-        if (wp.S > 1 && dense::dwide_blocks(K, N, true) >= 128) wp = dense::plan_dwide(K, N, true);
-        const int64_t need_w = 4096 + (wp.S > 1 ? dense_slab_bytes(M, N, wp.S) : 0);
-        TGIS_CHECK_ARG(workspace && workspace_bytes >= need_w, "tgis_dense_gemm: workspace too small (%ld < %ld)",
-                       (long)workspace_bytes, (long)need_w);
-        TgisTimedScope timed(TGIS_OP_DENSE_GEMM, st);
-        DenseArgs a;
-        DensePlan none{0, wp.S, dense::DWIDE_WK, wp.CT, 1};
-        dense_fill(a, x, ldx, prepared, bias, out, outf ? 0 : ldo, M, K, N, out_f32, (float*)((uint8_t*)workspace + 4096), 0, none);
-        a.gelu = gelu;
-        rc = dtype == TGIS_F16 ? launch_dwide<f16>(a, wp, act, outf, st) : launch_dwide<bf16>(a, wp, act, outf, st);
-        if (rc != TGIS_OK || wp.S == 1) return rc;
-        const int NP = a.NT * 32;
-        dim3 rgrid((unsigned)cdiv64((int64_t)32 * (NP / 4), 256), 1u);
-        if (dtype == TGIS_F16)
-            hipLaunchKernelGGL(dense_splitk_reduce_kernel<f16>, rgrid, dim3(256), 0, st, a.slabs, (const f16*)a.bias, a.out, a.ldo,
-                               a.M, a.N, NP, a.S, a.out_f32, a.gelu);
-        else
-            hipLaunchKernelGGL(dense_splitk_reduce_kernel<bf16>, rgrid, dim3(256), 0, st, a.slabs, (const bf16*)a.bias, a.out,
-                               a.ldo, a.M, a.N, NP, a.S, a.out_f32, a.gelu);
-        TGIS_CHECK_LAUNCH();
-        return TGIS_OK;
-    }
     DensePlan pl = plan_dense(K, N, M, act);
     TGIS_CHECK_ARG(act != 2 || (!out_f32 && pl.S == 1), "tgis_dense_gemm: act 2 writes the model dtype, unsplit");
     TGIS_CHECK_ARG(!gelu || !out_f32, "tgis_dense_gemm: act 4 / 5 (GELU) write the model dtype");
@@ -364,8 +279,6 @@ extern "C" int tgis_dense_gemm_rope(const void* x, int64_t ldx, const void* prep
                    "tgis_dense_gemm_rope: N must be (H + 2 Hkv) * D and q rows must hold H * D elements");
     hipStream_t st = (hipStream_t)stream;
     DensePlan pl = plan_dense_rope(K, N, M);  // as the SiLU epilogue: the whole k range in one block (S == 1)
-    const dense::DWidePlan wp = dense::plan_dwide(K, N, true);
-    if (ldx == TGIS_LD_FRAGMENTS) pl = DensePlan{0, 1, dense::DWIDE_WK, wp.CT, 1};
     TgisTimedScope timed(TGIS_OP_DENSE_GEMM, st);
     DenseArgs a;
     dense_fill(a, x, ldx, prepared, bias, q_out, ldq, M, K, N, 0, nullptr, 0, pl);
@@ -378,27 +291,12 @@ extern "C" int tgis_dense_gemm_rope(const void* x, int64_t ldx, const void* prep
     a.rH = (int)H;
     a.rHkv = (int)Hkv;
     a.rD = (int)D;
-    if (ldx == TGIS_LD_FRAGMENTS) return dtype == TGIS_F16 ? launch_dwide<f16>(a, wp, 3, false, st) : launch_dwide<bf16>(a, wp, 3, false, st);
     return dtype == TGIS_F16 ? launch_dense<f16>(a, pl, 3, cdiv64(M, 32), st) : launch_dense<bf16>(a, pl, 3, cdiv64(M, 32), st);
-}
-
-// Is an activation in fragment order (TGIS_LD_FRAGMENTS) served for this dense GEMM, and expected to beat the row-major launch?
-// act 0 (plain / partial / GELU), 2 (SiLU * up image), 3 (rope image: the fused qkv + rotary launch).  The epilogues that need
-// the finished sum keep the whole k range in a block: only while that still leaves >= 64 blocks.
-extern "C" int tgis_dense_fragments_ok(int64_t M, int64_t K, int64_t N, int act) {
-    if (K <= 0 || N <= 0 || !dense::dwide_serves(M, K, N)) return 0;
-    if (act != 0 && act != 2 && act != 3 && act != 4 && act != 5) return 0;
-    static const bool off = getenv("TGIS_DENSE_FRAGMENTS") && atoi(getenv("TGIS_DENSE_FRAGMENTS")) == 0;
-    if (off) return 0;
-    if (act != 0 && dense::dwide_blocks(K, N, true) < 64) return 0;
-    return 1;
 }
 
 extern "C" int64_t tgis_dense_gemm_partial_bytes(int64_t M, int64_t K, int64_t N) {
     DensePlan pl = plan_dense(K, N, M);
-    int64_t S = pl.S;
-    if (dense::dwide_serves(M, K, N)) S = std::max<int64_t>(S, dense::plan_dwide(K, N, false).S);
-    return dense_slab_bytes(std::max<int64_t>(M, 1), N, S);
+    return dense_slab_bytes(std::max<int64_t>(M, 1), N, pl.S);
 }
 
 extern "C" int tgis_dense_gemm_partial(const void* x, int64_t ldx, const void* prepared, int64_t M, int64_t K,
@@ -412,16 +310,6 @@ extern "C" int tgis_dense_gemm_partial(const void* x, int64_t ldx, const void* p
                    "tgis_dense_gemm_partial: slab buffer too small");
     hipStream_t st = (hipStream_t)stream;
     DensePlan pl = plan_dense(K, N, M);
-    if (ldx == TGIS_LD_FRAGMENTS) {
-        TGIS_CHECK_ARG(act == 0, "tgis_dense_gemm_partial: fragment-order activations: act 0");
-        const dense::DWidePlan wp = dense::plan_dwide(K, N, false);
-        if (num_slabs) *num_slabs = wp.S;
-        if (slab_ld) *slab_ld = cdiv64(N, 32) * 32;
-        TgisTimedScope timed(TGIS_OP_DENSE_GEMM, st);
-        DenseArgs a;
-        dense_fill(a, x, ldx, prepared, nullptr, nullptr, 0, M, K, N, 0, slabs, 1, DensePlan{0, wp.S, dense::DWIDE_WK, wp.CT, 1});
-        return dtype == TGIS_F16 ? launch_dwide<f16>(a, wp, 0, false, st) : launch_dwide<bf16>(a, wp, 0, false, st);
-    }
     if (num_slabs) *num_slabs = pl.S;
     if (slab_ld) *slab_ld = cdiv64(N, 32) * 32;
     TgisTimedScope timed(TGIS_OP_DENSE_GEMM, st);

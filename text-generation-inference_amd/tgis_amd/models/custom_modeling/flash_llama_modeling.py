@@ -166,7 +166,7 @@ class FlashLlamaAttention:
         T = qkv.shape[0]
         B = kv.block_tables.shape[0]
         if frag_rows(self.o_proj.linear, T, kv):  # decode: the o_proj GEMM reads its operand in fragment order
-            attn_output = native.FragAct.empty(T, H * D, qkv.device, qkv.dtype)
+            attn_output = native.FragAct.empty(T, H * D, qkv.device)
         else:
             attn_output = torch.empty((T, H * D), dtype=qkv.dtype, device=qkv.device)
         ws = None

@@ -52,7 +52,6 @@ SIGNATURES = {
     "tgis_gptq_rope_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_i64]),
     "tgis_gptq_fragments_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int]),
     "tgis_dense_rope_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64]),
-    "tgis_dense_fragments_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_int]),
     "tgis_gptq_gemm_rope_f16": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _c_i64,
                                          _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp]),
     "tgis_dense_prepared_bytes": (_c_i64, [_c_i64, _c_i64]),
@@ -202,13 +201,11 @@ LD_FRAGMENTS = -32
 
 
 class FragAct:
-    """A [M <= 64, K] f16 (int4 and dense GEMMs) or bf16 (dense GEMMs, M <= 32) activation stored in fragment order
-    (include/tgis_hip.h, TGIS_LD_FRAGMENTS): what the decode step's norm / attention / SiLU epilogue hand to the GEMM behind
-    them.  `buf` holds ceil(M / 32) * 32 * K elements."""
+    """A [M <= 64, K] f16 activation stored in fragment order (include/tgis_hip.h, TGIS_LD_FRAGMENTS): what the decode
+    step's norm / attention / SiLU epilogue hand to the int4 GEMM behind them.  `buf` holds ceil(M / 32) * 32 * K elements."""
 
     def __init__(self, buf: torch.Tensor, M: int, K: int):
-        assert 1 <= M <= 64 and K % 64 == 0 and buf.dtype in (torch.float16, torch.bfloat16)
-        assert buf.numel() == (M + 31) // 32 * 32 * K
+        assert 1 <= M <= 64 and K % 64 == 0 and buf.dtype == torch.float16 and buf.numel() == (M + 31) // 32 * 32 * K
         self.buf, self.M, self.K = buf, M, K
         self.dtype, self.device = buf.dtype, buf.device
 
@@ -217,8 +214,8 @@ class FragAct:
         return (self.M, self.K)
 
     @staticmethod
-    def empty(M: int, K: int, device, dtype=torch.float16) -> "FragAct":
-        return FragAct(torch.empty((M + 31) // 32 * 32 * K, dtype=dtype, device=device), M, K)
+    def empty(M: int, K: int, device) -> "FragAct":
+        return FragAct(torch.empty((M + 31) // 32 * 32 * K, dtype=torch.float16, device=device), M, K)
 
     @staticmethod
     def from_rows(x: torch.Tensor) -> "FragAct":
@@ -468,83 +465,52 @@ class DenseWeight:
         return load_library().tgis_dense_gemm_workspace_bytes(M, self.K, self.N)
 
 
-def dense_fragments_ok(M: int, w: DenseWeight, act: int = 0) -> bool:
-    """Should an M-row activation reach this dense GEMM in fragment order (tgis_dense_fragments_ok)?  act 2 = the gate | up image,
-    3 = the rope image, 4 / 5 = the GELU epilogue."""
-    key = ("frag_ok", M, act)
-    cache = w.__dict__.setdefault("_frag_ok", {})
-    got = cache.get(key)
-    if got is None:
-        got = cache[key] = bool(load_library().tgis_dense_fragments_ok(M, w.K, w.N, act))
-    return got
-
-
-def dense_gemm(x, w: DenseWeight, ws: Workspace, bias=None, out_f32: bool = False, act: int = 0, out=None,
-               out_frag: bool = False):
-    """x may be a FragAct (decode, M <= 32: the fragment-order kernel of dense_wide_body.h); the model-dtype result may then
-    leave as a FragAct too (out_frag) for the dense GEMM behind it."""
+def dense_gemm(x: torch.Tensor, w: DenseWeight, ws: Workspace, bias=None, out_f32: bool = False, act: int = 0,
+               out=None) -> torch.Tensor:
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == w.dtype
+    M = x.shape[0]
+    assert x.shape[1] == (2 * w.K if act == 1 else w.K)
     assert (act == 2) == bool(w.flags & 1), "act 2 runs on (and only on) a gate|up image"
-    if isinstance(x, FragAct):
-        assert x.K == w.K and x.dtype == w.dtype and act in (0, 2, 4, 5)
-        M, xp, ldx = x.M, _ptr(x.buf), LD_FRAGMENTS
-    else:
-        assert not out_frag, "a fragment-order output needs a fragment-order activation"
-        assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == w.dtype
-        M, xp, ldx = x.shape[0], _ptr(x), x.stride(0)
-        assert x.shape[1] == (2 * w.K if act == 1 else w.K)
-    n_out = w.N // 2 if act == 2 else w.N
-    if out_frag:
-        assert out is None and not out_f32
-        res = FragAct.empty(M, n_out, x.device, w.dtype)
-        optr, ldo = _ptr(res.buf), LD_FRAGMENTS
-    else:
-        res = out if out is not None else torch.empty((M, n_out), dtype=torch.float32 if out_f32 else w.dtype, device=x.device)
-        optr, ldo = _ptr(res), res.stride(0)
+    if out is None:
+        out = torch.empty((M, w.N // 2 if act == 2 else w.N), dtype=torch.float32 if out_f32 else w.dtype,
+                          device=x.device)
     ws.ensure(w.workspace_bytes(M))
     _check(
-        load_library().tgis_dense_gemm(xp, ldx, _ptr(w.image), _ptr(bias), optr, ldo, M, w.K, w.N, dtype_code(w.dtype),
-                                       int(out_f32), act, ws.ptr, ws.nbytes, _stream()), "tgis_dense_gemm")
-    return res
+        load_library().tgis_dense_gemm(_ptr(x), x.stride(0), _ptr(w.image), _ptr(bias), _ptr(out), out.stride(0), M,
+                                       w.K, w.N, dtype_code(w.dtype), int(out_f32), act, ws.ptr, ws.nbytes,
+                                       _stream()), "tgis_dense_gemm")
+    return out
 
 
-def dense_gemm_partial(x, w: DenseWeight, bias=None, act: int = 0) -> Partial:
+def dense_gemm_partial(x: torch.Tensor, w: DenseWeight, bias=None, act: int = 0) -> Partial:
     """Launch the dense GEMM but leave the split-K reduce (and bias) to the consumer kernel."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == w.dtype and x.shape[0] <= PARTIAL_MAX_M
     lib = load_library()
-    if isinstance(x, FragAct):
-        assert x.K == w.K and x.dtype == w.dtype and act == 0
-        M, xp, ldx = x.M, _ptr(x.buf), LD_FRAGMENTS
-    else:
-        assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == w.dtype and x.shape[0] <= PARTIAL_MAX_M
-        M, xp, ldx = x.shape[0], _ptr(x), x.stride(0)
-    nbytes = lib.tgis_dense_gemm_partial_bytes(M, w.K, w.N)
+    nbytes = lib.tgis_dense_gemm_partial_bytes(x.shape[0], w.K, w.N)
     slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     S = _c_int()
     ld = _c_i64()
     _check(
-        lib.tgis_dense_gemm_partial(xp, ldx, _ptr(w.image), M, w.K, w.N, dtype_code(w.dtype), act,
+        lib.tgis_dense_gemm_partial(_ptr(x), x.stride(0), _ptr(w.image), x.shape[0], w.K, w.N, dtype_code(w.dtype), act,
                                     _ptr(slabs), nbytes, ctypes.byref(S), ctypes.byref(ld), _stream()),
         "tgis_dense_gemm_partial")
-    p = Partial(slabs, S.value, ld.value, M, w.N, bias)
+    p = Partial(slabs, S.value, ld.value, x.shape[0], w.N, bias)
     p.dtype = w.dtype
     return p
 
 
-def dense_gemm_rope(x, w: DenseWeight, bias, cos, sin, positions, slots, k_pool, v_pool, H: int, Hkv: int,
+def dense_gemm_rope(x: torch.Tensor, w: DenseWeight, bias, cos, sin, positions, slots, k_pool, v_pool, H: int, Hkv: int,
                     D: int, out=None) -> torch.Tensor:
     """Dense qkv projection + rotary embedding + cache write in one launch (decode, M <= 64; `w` is the rope image of the
-    fused qkv weight).  Returns [M, (H + 2 Hkv) D] whose first H D columns hold the rotated q.  x may be a FragAct (M <= 32)."""
-    if isinstance(x, FragAct):
-        assert x.K == w.K and x.dtype == w.dtype
-        M, xp, ldx = x.M, _ptr(x.buf), LD_FRAGMENTS
-    else:
-        assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == w.dtype and x.shape[1] == w.K
-        M, xp, ldx = x.shape[0], _ptr(x), x.stride(0)
+    fused qkv weight).  Returns [M, (H + 2 Hkv) D] whose first H D columns hold the rotated q."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == w.dtype and x.shape[1] == w.K
     assert w.flags & 2 and w.N == (H + 2 * Hkv) * D and cos.dtype == w.dtype and cos.shape[1] * 2 == D
     assert positions.dtype == torch.int32 and slots.dtype == torch.int32
+    M = x.shape[0]
     if out is None:
         out = torch.empty((M, w.N), dtype=w.dtype, device=x.device)
     _check(
-        load_library().tgis_dense_gemm_rope(xp, ldx, _ptr(w.image), _ptr(bias), _ptr(positions), _ptr(slots),
+        load_library().tgis_dense_gemm_rope(_ptr(x), x.stride(0), _ptr(w.image), _ptr(bias), _ptr(positions), _ptr(slots),
                                             _ptr(cos), _ptr(sin), _ptr(out), out.stride(0), _ptr(k_pool), _ptr(v_pool), M,
                                             w.K, w.N, H, Hkv, D, dtype_code(w.dtype), _stream()),
         "tgis_dense_gemm_rope")
@@ -563,8 +529,8 @@ def rmsnorm_residual(x, residual, weight, eps: float, y=None, res_out=None, frag
     rows, hidden = x.shape
     yf = None
     if frag:
-        assert y is None and rows <= 64 and hidden % 64 == 0 and x.dtype in (torch.float16, torch.bfloat16)
-        yf = FragAct.empty(rows, hidden, x.device, x.dtype)
+        assert y is None and rows <= 64 and hidden % 64 == 0 and x.dtype == torch.float16
+        yf = FragAct.empty(rows, hidden, x.device)
         y, ldy = yf.buf, LD_FRAGMENTS
     else:
         ldy = hidden

@@ -78,37 +78,14 @@ class FastLinear:
             # the image is a second copy of the weight: only build it where the fused launch will serve some decode batch
             # (tgis_dense_rope_ok asks for >= TGIS_ROPE_MIN_BLOCKS workgroups in the unsplit plan — TinyLlama has 40, a
             # 70B shard at TP = 8 has 20), as Ex4bitLinearV2.post_init does for the int4 image
-            if any(native.rope_gemm_ok(m, self.prepared, D) for m in (1, 32, 64)) or any(
-                    native.dense_fragments_ok(m, self.prepared, 3) for m in (1, 32)):
+            if any(native.rope_gemm_ok(m, self.prepared, D) for m in (1, 32, 64)):
                 self.rope_handle = native.DenseWeight(self.weight, rope=(D, H + Hkv))
 
-    def wants_fragments(self, rows: int, act: int = 0) -> bool:
-        """Should the producer of this linear's operand write it in fragment order (native.FragAct) for `rows` decode rows?
-        act: 0 plain / partial, 2 the SiLU * up image, 3 the rope image (the fused qkv + rotary launch).  Round 5: the dense
-        decode GEMMs have the fragment-order kernel too (dense_wide_body.h), f16 and bf16, up to 32 rows."""
-        if act == 2 and not self._gate_up:
-            act = 0
-        w = self.rope_handle if act == 3 else self.prepared
-        return w is not None and rows <= 32 and native.dense_fragments_ok(rows, w, act)
-
-    def forward(self, x, act: int = 0, out_f32: bool = False, partial: bool = False,
-                gelu: Optional[bool] = None, out_frag: bool = False) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, act: int = 0, out_f32: bool = False, partial: bool = False,
+                gelu: Optional[bool] = None) -> torch.Tensor:
         """`gelu` (None / False: exact erf form / True: tanh approximation): the activation behind this projection
         (santacoder's `c_fc`, flash_santacoder_modeling.py:303-305) — applied where the decode GEMM finishes its output
-        instead of by a launch of its own; same bits as the two steps.
-        x may be a native.FragAct (decode, <= 32 rows; see wants_fragments); out_frag: the output leaves as one."""
-        if isinstance(x, native.FragAct):
-            assert act == 0
-            if self._gate_up:
-                return native.dense_gemm(x, self.prepared, workspace(x.device), bias=self.bias, act=2, out_frag=out_frag)
-            if gelu is not None:
-                return native.dense_gemm(x, self.prepared, workspace(x.device), bias=self.bias, act=5 if gelu else 4,
-                                         out_frag=out_frag)
-            if partial and DEFER_REDUCE and not out_f32:
-                return native.dense_gemm_partial(x, self.prepared, bias=self.bias)
-            return native.dense_gemm(x, self.prepared, workspace(x.device), bias=self.bias, out_f32=out_f32,
-                                     out_frag=out_frag)
-        assert not out_frag, "a fragment-order output needs a fragment-order activation"
+        instead of by a launch of its own; same bits as the two steps."""
         if gelu is not None:
             assert act == 0 and not out_f32 and not partial and not self._gate_up
             if x.shape[0] <= SKINNY_MAX_M and FUSED_GELU_GEMM:
