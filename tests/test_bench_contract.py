@@ -39,3 +39,18 @@ def test_algorithmic_bytes_match_the_survey_worked_numbers():
     ab = bench.algorithmic_bytes_per_step(LlamaConfig(**kw), quantize, B, ctx, tp=1)
     assert abs(ab["total"] - 20.8e9) / 20.8e9 < 0.01  # ~20.8 GB per cfg3 decode step
     assert abs(ab["total"] / 8e12 * 1e3 - 2.60) < 0.02  # 2.60 ms at 8 TB/s
+
+
+def test_round5_bench_line_reports_the_median_of_three_timed_blocks():
+    """three timed blocks of `steps` steps inside one invocation; ms_per_step / value are the median block,
+    ms_per_step_range its fastest and slowest (profiles/r05b_bench_cfg3.json is a line printed by this tree's bench.py)."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05b_bench_cfg3.json")))
+    blocks = d["ms_per_step_blocks"]
+    assert d["timed_blocks"] == 3 and len(blocks) == 3
+    assert d["ms_per_step"] == sorted(blocks)[1]
+    assert d["ms_per_step_range"] == [min(blocks), max(blocks)]
+    B = d["config"]["global_batch"]
+    assert abs(d["value"] - B / d["ms_per_step"] * 1e3) / d["value"] < 1e-3
+    for k in ("roofline", "cpu_baseline", "step_roofline"):
+        assert k in d, k
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
