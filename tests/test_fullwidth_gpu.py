@@ -227,6 +227,23 @@ def _free_port():
     return p
 
 
+def _spawn(fn, args, nprocs):
+    """mp.spawn with the host threads of every rank capped: eight ranks that each start a full OpenMP / MKL team while they
+    import torch, build tensors and create their HIP context spend most of their start-up fighting for the cores."""
+    keys = ("OMP_NUM_THREADS", "MKL_NUM_THREADS")
+    old = {k: os.environ.get(k) for k in keys}
+    for k in keys:
+        os.environ[k] = str(max(1, (os.cpu_count() or 8) // nprocs))
+    try:
+        mp.spawn(fn, args=args, nprocs=nprocs, join=True)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def _tp_worker(rank, world, port, ret, case="cfg4", tensor_path=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       TGIS_DIST_BACKEND="gloo", TGIS_ALLOW_SHARED_GPU="1", TGIS_DIST_TIMEOUT_S="900")
@@ -277,7 +294,7 @@ def test_cfg4_tp8_shard_shapes_match_oracle(gpu_device):
     cfg, tensors = _make("llama", kw, layers, quantize, dtype, seed=4321)
     path = _shared_tensor_file(tensors)
     try:
-        mp.spawn(_tp_worker, args=(8, _free_port(), ret, "cfg4", path), nprocs=8, join=True)
+        _spawn(_tp_worker, (8, _free_port(), ret, "cfg4", path), 8)
     finally:
         os.unlink(path)
     t1 = time.time()
@@ -304,7 +321,7 @@ def test_cfg5_tp4_shard_shapes_match_oracle(gpu_device):
     cfg, tensors = _make(family, kw, layers, quantize, dtype, seed=4321)
     path = _shared_tensor_file(tensors)
     try:
-        mp.spawn(_tp_worker, args=(4, _free_port(), ret, "cfg5", path), nprocs=4, join=True)
+        _spawn(_tp_worker, (4, _free_port(), ret, "cfg5", path), 4)
     finally:
         os.unlink(path)
     t1 = time.time()

@@ -29,6 +29,23 @@ def _free_port():
     return p
 
 
+def _spawn(fn, args, nprocs):
+    """mp.spawn with the host threads of every rank capped: eight ranks that each start a full OpenMP / MKL team while they
+    import torch, build tensors and create their HIP context spend most of their start-up fighting for the cores."""
+    keys = ("OMP_NUM_THREADS", "MKL_NUM_THREADS")
+    old = {k: os.environ.get(k) for k in keys}
+    for k in keys:
+        os.environ[k] = str(max(1, (os.cpu_count() or 8) // nprocs))
+    try:
+        mp.spawn(fn, args=args, nprocs=nprocs, join=True)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def _graph_info(lm):
     """(mode, captured segments per decode graph) of the model's decode graphs."""
     if not lm.use_graphs:
@@ -94,7 +111,7 @@ def _worker(rank, world, port, quantize, inter, ret, cfg_kw=None):
 def test_tp2_product_path_matches_oracle(gpu_device, quantize, inter):
     mgr = mp.get_context("spawn").Manager()  # never fork a process that has run gRPC (or CUDA) threads
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), quantize, inter, ret), nprocs=2, join=True)
+    _spawn(_worker, (2, _free_port(), quantize, inter, ret), 2)
     ids0, logits0 = ret[0]
     ids1, logits1 = ret[1]
     assert ids0 == ids1, "ranks must stay in lock-step without a broadcast"
@@ -120,7 +137,7 @@ def test_tp8_shapes_match_oracle(gpu_device):
     inter = 2816
     mgr = mp.get_context("spawn").Manager()  # never fork a process that has run gRPC (or CUDA) threads
     ret = mgr.dict()
-    mp.spawn(_worker, args=(8, _free_port(), "gptq", inter, ret, kw), nprocs=8, join=True)
+    _spawn(_worker, (8, _free_port(), "gptq", inter, ret, kw), 8)
     ids0, logits0 = ret[0]
     for r in range(1, 8):
         assert ret[r][0] == ids0
@@ -191,7 +208,7 @@ def test_tp_santacoder_mqa_matches_oracle(gpu_device, world):
 
     mgr = mp.get_context("spawn").Manager()  # never fork a process that has run gRPC (or CUDA) threads
     ret = mgr.dict()
-    mp.spawn(_bigcode_worker, args=(world, _free_port(), "float16", ret), nprocs=world, join=True)
+    _spawn(_bigcode_worker, (world, _free_port(), "float16", ret), world)
     ids0, logits0 = ret[0]
     for r in range(1, world):
         assert ret[r][0] == ids0 and all(np.array_equal(a, b) for a, b in zip(ret[r][1], logits0))
@@ -212,7 +229,7 @@ def test_tp2_segmented_graphs_equal_eager(gpu_device, monkeypatch):
         monkeypatch.setenv("TGIS_TP_GRAPHS", mode)
         mgr = mp.get_context("spawn").Manager()
         ret = mgr.dict()
-        mp.spawn(_worker, args=(2, _free_port(), "gptq", 512, ret), nprocs=2, join=True)
+        _spawn(_worker, (2, _free_port(), "gptq", 512, ret), 2)
         got[mode] = (ret[0], ret["graph0"], ret["graph1"])
     (ids_s, logits_s), info_s, info_s1 = got["segments"]
     (ids_e, logits_e), info_e, _ = got["false"]
@@ -231,7 +248,7 @@ def test_tp2_sampling_ranks_agree(gpu_device):
     mix(base, arrival number))."""
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), "gptq", 512, ret, {"_sample": True}), nprocs=2, join=True)
+    _spawn(_worker, (2, _free_port(), "gptq", 512, ret, {"_sample": True}), 2)
     ids0, logits0 = ret[0]
     ids1, logits1 = ret[1]
     assert ids0 == ids1
