@@ -126,13 +126,18 @@ __device__ __forceinline__ void norm_row(const NormPhase& p, const int row, floa
         const int c = threadIdx.x + it * nthreads;
         if (c < nchunk) {
             wv[it] = ld16<V8>(reinterpret_cast<const T*>(p.weight) + c * 8);
+            // Round 5: the residual and the bias of the GEMM before are requested HERE, in front of the slabs.  Behind them (in
+            // their own basic blocks, after the waits of the slab sum) they were a second and a third dependent round trip to
+            // memory in a kernel that is nothing but one round trip (ISA of norm_kernel<f16, true, true, 512>).
+            V8 b, bv;
+            if (rr) b = ld16<V8>(rr + c * 8);
+            if (p.slabs && xb) bv = ld16<V8>(xb + c * 8);
             V8 a;
             if (p.slabs) {
                 f32x4 lo, hi;
                 sum_slabs8(p.slabs + ((int64_t)(row >> 5) * p.S * 32 + (row & 31)) * p.slab_ld + c * 8, 32 * p.slab_ld, p.S,
                            lo, hi);
                 if (xb) {
-                    const V8 bv = ld16<V8>(xb + c * 8);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         lo[e] += to_f32(bv[e]);
@@ -148,7 +153,6 @@ __device__ __forceinline__ void norm_row(const NormPhase& p, const int row, floa
                 a = ld16<V8>(xr + c * 8);
             }
             if (rr) {
-                const V8 b = ld16<V8>(rr + c * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[it][e] = to_f32(a[e]) + to_f32(b[e]);
             } else {

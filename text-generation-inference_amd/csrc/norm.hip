@@ -69,13 +69,16 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
         if (c < nchunk) {
             wvs[it] = ld16<V8>(weight + c * 8);
             if (bias) bvs[it] = ld16<V8>(bias + c * 8);
+            // (round 5: residual and GEMM bias requested in front of the slabs, as in gsync::norm_row)
+            V8 b, bv;
+            if (rr) b = ld16<V8>(rr + c * 8);
+            if (PARTIAL && xbias) bv = ld16<V8>(xbias + c * 8);
             V8 a;
             if (PARTIAL) {
                 f32x4 lo, hi;
                 // slabs are stored in 32-row units: [row / 32][S][32][slab_ld]
                 sum_slabs8(slabs + ((int64_t)(row >> 5) * S * 32 + (row & 31)) * slab_ld + c * 8, 32 * slab_ld, S, lo, hi);
                 if (xbias) {
-                    V8 bv = ld16<V8>(xbias + c * 8);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         lo[e] += to_f32(bv[e]);
@@ -92,7 +95,6 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
             }
             V8 o;
             if (rr) {
-                V8 b = ld16<V8>(rr + c * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[it][e] = to_f32(a[e]) + to_f32(b[e]);
             } else {
