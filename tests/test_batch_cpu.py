@@ -49,6 +49,26 @@ def test_from_pb_left_truncation_and_bos():
     assert b.input_ids.tolist() == [1, 8, 9]  # last 3 tokens kept, BOS re-inserted in front
 
 
+def test_pages_are_taken_lowest_first_and_page_major():
+    """kv_cache.py: the pool hands out its lowest free ids, and a batch lays them PAGE-major over its sequences (what the
+    decode blocks read at one instant is then a dense run of the pool); a finished sequence's pages are the next ones out."""
+    cache = PagedKVCache(1, 1, 64, 32, torch.float16, CPU)
+    a = _batch([[5] * 70, [6] * 33, [7] * 3], 40, batch_id=1)   # 3 + 2 + 1 pages
+    a.allocate_pages(cache)
+    assert a.pages == [[0, 3, 5], [1, 4], [2]]
+    a.input_lengths = [97, 65, 4]
+    a.grow_pages()                                              # the two sequences that cross a page: neighbours again
+    assert a.pages == [[0, 3, 5, 6], [1, 4, 7], [2]]
+    cache.free(a.pages[1])
+    b = _batch([[8] * 40], 5, first_id=5, batch_id=2)
+    b.allocate_pages(cache)
+    assert b.pages == [[1, 4]] and cache.free_pages == 32 - 8 + 3 - 2
+    a.pages[1] = []
+    a.release()
+    b.release()
+    assert cache.free_pages == 32 and cache.alloc(4) == [0, 1, 2, 3]
+
+
 def test_page_ownership_concat_prune_release():
     cache = PagedKVCache(2, 2, 64, 16, torch.float16, CPU)
     a = _batch([[5] * 70, [6] * 33], 40, batch_id=1)         # prompt + first token: 71 and 34 slots -> 3 + 2 pages

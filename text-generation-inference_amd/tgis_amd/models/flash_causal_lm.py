@@ -85,10 +85,13 @@ class FlashCausalLMBatch(Batch):
         need = [PagedKVCache.pages_for(n + 1) for n in self.input_lengths]
         flat = kv_cache.alloc(sum(need))  # raises OutOfPages before anything is taken
         self.kv_cache = kv_cache
-        self.pages, o = [], 0
-        for n in need:
-            self.pages.append(flat[o:o + n])
-            o += n
+        # page-major: page p of every sequence, then page p + 1 (kv_cache.py: the pages the decode blocks read at the same
+        # time are then neighbours in the pool)
+        self.pages, it = [[] for _ in need], iter(flat)
+        for p in range(max(need, default=0)):
+            for own, n in zip(self.pages, need):
+                if p < n:
+                    own.append(next(it))
         self._rebuild_block_tables()
 
     def grow_pages(self):

@@ -7,6 +7,7 @@ The *logical* slot index the reference exposes (`cu_seqlens[1:] - 1`, flash_llam
 by FlashCausalLMBatch; `PagedKVCache` only maps (request, position) -> physical (page, offset).
 Design cue for paging: models/paged_causal_lm.py:300-348 (block size 16 there; 32 here = one MFMA K=32 step).
 """
+import heapq
 from typing import List
 
 import torch
@@ -24,10 +25,13 @@ class PagedKVCache:
         self.num_pages = num_pages
         # zero-initialised: masked slots are multiplied by P = 0, so they must never hold NaN/Inf patterns
         self.pool = torch.zeros((num_layers, 2, num_pages, num_kv_heads, PAGE * head_dim), dtype=dtype, device=device)
-        # hand pages out in a fixed pseudo-random order: a sequence's consecutive pages would otherwise sit at a
-        # constant Hkv*page stride, and equal-phase waves of the decode kernel would camp on the same HBM channels
-        order = torch.randperm(num_pages, generator=torch.Generator().manual_seed(0x5eed)).tolist()
-        self._free = order
+        # Pages are handed out lowest id first, and a batch spreads what it takes PAGE-MAJOR over its sequences
+        # (FlashCausalLMBatch.allocate_pages: page p of every sequence before page p + 1 of any): the decode kernel's blocks
+        # walk their sequences' pages in step, so what the chip reads at one instant is then one dense run of the pool,
+        # spread evenly over the HBM channels.  Measured at the cfg3 shape (tools/attn_page_order.py, profiles/
+        # r05_attn_page_order.log): page-major 80.7 us, a random order (rounds 1-4) 82.6, a sequence's pages next to each
+        # other 88-92 (equal-phase blocks camp on the same channels).  A pool that has churned degrades to the random case.
+        self._free = list(range(num_pages))  # a heap (heapq), trivially one to begin with
 
     @property
     def free_pages(self) -> int:
@@ -43,14 +47,14 @@ class PagedKVCache:
         return self.pool[layer, 1]
 
     def alloc(self, n: int) -> List[int]:
+        """The n lowest free page ids, ascending."""
         if n > len(self._free):
             raise OutOfPages(f"KV cache exhausted: need {n} pages, {len(self._free)} free of {self.num_pages}")
-        out = self._free[-n:][::-1] if n else []
-        del self._free[len(self._free) - n:]
-        return out
+        return [heapq.heappop(self._free) for _ in range(n)]
 
     def free(self, pages: List[int]):
-        self._free.extend(reversed(pages))
+        for p in pages:
+            heapq.heappush(self._free, p)
 
     @staticmethod
     def pages_for(tokens: int) -> int:

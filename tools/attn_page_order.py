@@ -1,0 +1,88 @@
+"""Round 5: does the ORDER of a batch's pages in the pool move the decode attention launch?  (bench.py's first timed block — the
+first batch of a fresh pool, pages in allocation order — is always 0.1-0.2 ms per step slower than the blocks after it, whose
+batches take recycled pages.)  cfg3 shape: B 32, 32 heads, D 128, ctx 1023; block tables: random, sequential (b * P + p),
+page-major (p * B + b), reversed sequential.  -> stdout"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "text-generation-inference_amd"))
+from tgis_amd import native as nat  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=60, reps=5):
+    for i in range(6):
+        fn(i)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(iters):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters)
+    return best * 1e3
+
+
+def main():
+    B, H, Hkv, D, ctx, sets = 32, 32, 32, 128, 1023, 6
+    P = (ctx + 31) // 32
+    total = B * P
+    cap = 2 * total  # pool twice the batch: fragmented orders below
+    pools = [(torch.randn(cap, Hkv, 32 * D, device=dev).half(), torch.randn(cap, Hkv, 32 * D, device=dev).half())
+             for _ in range(sets)]
+    q = torch.randn(B, H * D, device=dev).half()
+    ctxl = torch.full((B,), ctx, dtype=torch.int32, device=dev)
+    cu = torch.arange(B + 1, dtype=torch.int32, device=dev)
+    out = torch.empty(B, H * D, device=dev, dtype=torch.float16)
+    ns = nat.attn_num_splits(B, Hkv, H, 1, ctx)
+    ws = nat.Workspace(nat.attn_workspace_bytes(B, H, Hkv, D, ns), dev)
+    seq = torch.arange(total, device=dev).int().view(B, P)
+    orders = {
+        "random": torch.randperm(total, device=dev).int().view(B, P),
+        "sequential b*P+p": seq,
+        "page-major p*B+b": torch.arange(total, device=dev).int().view(P, B).t(),
+        "reversed": (total - 1 - seq),
+        "random rows, sequential inside": seq[torch.randperm(B, device=dev)],
+        "page-major, rows shuffled per p": torch.stack([p * B + torch.randperm(B, device=dev) for p in range(P)], 1).int(),
+        "page-major in pairs of pages": ((torch.arange(P, device=dev) // 2) * 2 * B + torch.arange(P, device=dev) % 2)[None, :].int()
+                                        + 2 * torch.arange(B, device=dev)[:, None].int(),
+        "page-major, every second id": 2 * torch.arange(total, device=dev).int().view(P, B).t(),
+        "page-major over a sorted random half": torch.sort(torch.randperm(cap, device=dev)[:total]).values.int().view(P, B).t(),
+        "random over the 2x pool": torch.randperm(cap, device=dev)[:total].int().view(B, P),
+    }
+    print(nat.version(), torch.cuda.get_device_name(0), f"splits {ns}")
+    for rnd in range(2):
+        print(f' round {rnd}')
+        for name, bt in orders.items():
+            bt = bt.contiguous()
+            t = timeit(lambda i: nat.attn_paged(q, H * D, pools[i % sets][0], pools[i % sets][1], bt, ctxl, cu, out, B, H, Hkv, D, 1,
+                                                ctx, D ** -0.5, ns, ws))
+            print(f"  {name:34s} {t:7.2f} us   {B * ctx * 2 * Hkv * D * 2 / t / 1e6:6.2f} TB/s")
+
+    # where the V pool sits relative to the K pool (page-major tables): the product's pool is [layer][K | V][page], i.e. V at
+    # num_pages * 256 KiB behind K; "interleaved" emulates a [page][K | V] pool (V one page behind K, even page ids only)
+    print(" V pool offset (page-major tables)")
+    page = Hkv * 32 * D
+    bigs = [torch.randn((2 * cap + 64) * page, device=dev).half() for _ in range(sets)]
+    pm = torch.arange(total, device=dev).int().view(P, B).t().contiguous()
+    cases = {"V = K + cap pages (as the product)": (cap * page, pm),
+             "V = K + cap pages + 4 KiB": (cap * page + 2048, pm),
+             "V = K + cap pages + 64 KiB": (cap * page + 32768, pm),
+             "V = K + cap pages + 128 KiB": (cap * page + 65536, pm),
+             "V = K + total pages (dense K, then dense V)": (total * page, pm),
+             "interleaved [page][K | V]": (page, (2 * pm).contiguous())}
+    for rnd in range(2):
+        for name, (voff, bt) in cases.items():
+            t = timeit(lambda i: nat.attn_paged(q, H * D, bigs[i % sets], bigs[i % sets][voff:], bt, ctxl, cu, out, B, H, Hkv, D, 1,
+                                                ctx, D ** -0.5, ns, ws))
+            print(f"  {name:46s} {t:7.2f} us   {B * ctx * 2 * Hkv * D * 2 / t / 1e6:6.2f} TB/s")
+
+
+if __name__ == "__main__":
+    main()
