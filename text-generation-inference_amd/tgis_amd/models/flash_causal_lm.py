@@ -88,10 +88,13 @@ class FlashCausalLMBatch(Batch):
         # page-major: page p of every sequence, then page p + 1 (kv_cache.py: the pages the decode blocks read at the same
         # time are then neighbours in the pool)
         self.pages, it = [[] for _ in need], iter(flat)
-        for p in range(max(need, default=0)):
-            for own, n in zip(self.pages, need):
-                if p < n:
-                    own.append(next(it))
+        g = int(os.getenv("TGIS_KV_PAGE_GROUP", "0")) or len(need)
+        for g0 in range(0, len(need), g):
+            grp = range(g0, min(g0 + g, len(need)))
+            for p in range(max((need[i] for i in grp), default=0)):
+                for i in grp:
+                    if p < need[i]:
+                        self.pages[i].append(next(it))
         self._rebuild_block_tables()
 
     def grow_pages(self):

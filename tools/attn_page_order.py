@@ -84,5 +84,49 @@ def main():
             print(f"  {name:46s} {t:7.2f} us   {B * ctx * 2 * Hkv * D * 2 / t / 1e6:6.2f} TB/s")
 
 
+def grouped(B, P, g, dev_):
+    """page-major inside groups of g sequences (group after group in the pool)"""
+    b = torch.arange(B, device=dev_)[:, None]
+    p = torch.arange(P, device=dev_)[None, :]
+    return ((b // g) * (g * P) + p * g + b % g).int().contiguous()
+
+
+def more_rounds(B=64, H=32, Hkv=32, D=128, ctx=1023, sets=4):
+    """B = 64 at the cfg3 width: 2048 blocks = two rounds of the 1024 that fit; which sequences' pages should be neighbours?"""
+    P = (ctx + 31) // 32
+    total = B * P
+    pools = [(torch.randn(total, Hkv, 32 * D, device=dev).half(), torch.randn(total, Hkv, 32 * D, device=dev).half())
+             for _ in range(sets)]
+    q = torch.randn(B, H * D, device=dev).half()
+    ctxl = torch.full((B,), ctx, dtype=torch.int32, device=dev)
+    cu = torch.arange(B + 1, dtype=torch.int32, device=dev)
+    out = torch.empty(B, H * D, device=dev, dtype=torch.float16)
+    ns = nat.attn_num_splits(B, Hkv, H, 1, ctx)
+    ws = nat.Workspace(nat.attn_workspace_bytes(B, H, Hkv, D, ns), dev)
+    orders = {"random": torch.randperm(total, device=dev).int().view(B, P).contiguous(),
+              "page-major over all B": grouped(B, P, B, dev)}
+    for g in (32, 16, 8, 4, 2):
+        if g < B:
+            orders[f"page-major in groups of {g} sequences"] = grouped(B, P, g, dev)
+    print(f" B {B} H {H} Hkv {Hkv} ctx {ctx} splits {ns}")
+    for rnd in range(2):
+        for name, bt in orders.items():
+            t = timeit(lambda i: nat.attn_paged(q, H * D, pools[i % sets][0], pools[i % sets][1], bt, ctxl, cu, out, B, H, Hkv, D, 1,
+                                                ctx, D ** -0.5, ns, ws), iters=30)
+            print(f"  {name:42s} {t:7.2f} us   {B * ctx * 2 * Hkv * D * 2 / t / 1e6:6.2f} TB/s")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "rounds":
+        more_rounds(B=32)                            # cfg3
+        more_rounds(B=64)                            # cfg3 at B = 64: two rounds of blocks
+        more_rounds(B=16)
+        more_rounds(B=8)
+        more_rounds(B=32, H=16, Hkv=16)              # a cfg3 rank at TP 2
+        more_rounds(B=32, H=4, Hkv=4)                # ... at TP 8
+        more_rounds(B=64, H=64, Hkv=8, ctx=2047, sets=2)   # cfg4 on one GPU
+        more_rounds(B=64, H=8, Hkv=1, ctx=2047)      # a cfg4 rank at TP 8
+        more_rounds(B=32, H=48, Hkv=1, ctx=4095)     # cfg5
+        more_rounds(B=16, H=32, Hkv=4, ctx=511)      # cfg2
+        sys.exit(0)
     main()
