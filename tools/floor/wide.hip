@@ -51,6 +51,8 @@ struct Args {
     float* slabs;          // [S][32][NT*32]
     int M, K, N, NT, KS, G, spg_shift;
     int S, steps;          // global splits, real k64-steps (K / 64)
+    int lay;               // wide2_gemm, timing only (results are wrong): 0 = the prepared image [tile][step]; 1 = step-major
+                           // [local step][tile][k part] (what all waves read at one instant is one dense run); 2 = [local step][k part][tile]
     long long* trace;      // [blocks][WK][8] s_memtime stamps (nullptr: off)
     // EPI 3.. (rope epilogue as in gptq_wide_body.h ACT 3)
     const int32_t* positions; const int32_t* slots; const f16* cosb; const f16* sinb; f16* kpool; f16* vpool;
@@ -607,6 +609,11 @@ __global__ __launch_bounds__(64 * WK) void wide2_gemm(Args a) {
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
             const char* p = wt[t] + (int64_t)sc * 1024;
+            if (a.lay) {
+                const int64_t nt = min(cg * CT + t, a.NT - 1), parts = (int64_t)WK * a.S, part = split * WK + wk;
+                const int64_t idx = a.lay == 1 ? ((int64_t)(sc - s0) * a.NT + nt) * parts + part : ((int64_t)(sc - s0) * parts + part) * a.NT + nt;
+                p = reinterpret_cast<const char*>(a.prep) + min(idx, (int64_t)a.NT * a.KS - 1) * 1024;
+            }
             PIN_SGPR(p);
             wq[d][t] = __builtin_nontemporal_load((const GLOBAL_AS u32x4*)(p + woff));
         }
@@ -997,6 +1004,7 @@ static float run2(const Image& im, const std::vector<uint8_t*>& sets, const f16*
     a.x = dx; a.ldx = im.K; a.xf = g_xf; a.out = dout; a.ldo = im.N; a.slabs = dslabs;
     a.M = M; a.K = im.K; a.N = im.N; a.NT = im.NT; a.KS = im.KS; a.G = im.G;
     a.offB = im.offB; a.S = S; a.steps = im.K / 64; a.trace = nullptr;
+    a.lay = getenv("WIDE_LAY") ? atoi(getenv("WIDE_LAY")) : 0;
     int spg = im.gs / 64, sh = 0;
     while ((1 << sh) < spg) ++sh;
     a.spg_shift = sh;
@@ -1181,6 +1189,10 @@ int main(int argc, char** argv) {
                 R2(2, 8, 2, 2, 4, 1, 1, 1, 1); R2(2, 8, 2, 2, 4, 1, 0, 1, 0, 1); R2(2, 8, 2, 2, 4, 1, 0, 1, 1, 1); R2(2, 8, 2, 2, 3, 1, 0, 1, 1); R2(2, 8, 2, 2, 3, 1, 0, 1, 2);
                 R2(2, 8, 2, 2, 2, 1, 0, 1, 2); R2(2, 8, 2, 2, 2, 1, 0, 1, 3);
             }
+        } else if (!strcmp(suite, "r05l")) {   // the shipped plans; run with WIDE_LAY=0 / 1 / 2 (weight address order, timing only)
+            if (sh.N == 12288) { R2(2, 8, 2, 2, 1, 1, 0, 1); R2(2, 8, 4, 2, 1, 1, 0, 1); }
+            else if (sh.N == 22016) { R2(3, 8, 2, 2, 1, 1, 0, 1); R2(3, 8, 4, 2, 1, 1, 0, 1); }
+            else { R2(2, 8, 2, 2, 4, 1, 0, 1); R2(2, 8, 4, 2, 4, 1, 0, 1); R2(2, 8, 2, 2, 2, 1, 0, 1); }
         } else if (!strcmp(suite, "r05d")) {   // what bounds the loop?  ablations of the round-4 kernel (wrong results by design)
             // 0 full; 1 no arithmetic; 2 no x loads; 6 no dequantisation; 5 weights + scales only; 4 weights only;
             // 8 x always from the same 4 KiB (L1 hits); 9 one x load per step instead of four
