@@ -291,6 +291,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--ctx", type=int, default=None, help="mean context length over the timed steps")
     ap.add_argument("--blocks", type=int, default=3, help="timed blocks of --steps steps each; the median block is reported")
+    ap.add_argument("--dump-steps", action="store_true", help="stderr: the host-side time of every timed step, per block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -406,6 +407,9 @@ def main():
         order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
         elapsed, step_ms = blocks[order[len(order) // 2]]
         block_ms_per_step = [round(b[0] / K * 1e3, 4) for b in blocks]
+        if args.dump_steps and rank == 0:
+            for i, b in enumerate(blocks):
+                print(f"block {i}: " + " ".join(f"{v:.3f}" for v in b[1]), file=sys.stderr)
         coll_us = graph_segments.collective_times_us() if tp > 1 else []
         graph_segments.time_collectives(False)
         ctx_timed_mean = L_in + 1 + W + (K - 1) / 2.0  # keys attended per step, averaged over the timed steps

@@ -210,6 +210,27 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) vf[nb] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(vb + nb * 128));
     };
+    // The page a sequence is still filling: only the cache lines of its nv written tokens are requested (round 5: the launch
+    // cost one whole page per started page — bench.py's steps got 0.1 ms slower the moment the batch crossed a page
+    // boundary, and the counters saw 1.016 x the algorithmic bytes).  K interleaves a tile's 16 tokens at 16 bytes (a lane is
+    // one token), V keeps tokens 4 g .. 4 g + 3 of both tiles in column group g (a lane is one group): the lanes of unwritten
+    // tile is not requested while the sequence fills the first one (its registers repeat the first tile: finite values whose
+    // scores are masked), the lanes of unwritten V groups re-read group 0 (lines the wave requests anyway; their P is exactly
+    // 0) — addresses move, no lane is switched off.  (Redirecting the unwritten tokens of the tile that IS being filled as
+    // well costs 6 - 9 more VGPRs, i.e. the third wave per SIMD that the many-block shapes need; not done.)
+    auto load_page_part = [&](const int pg, const int nv, V8 (&kf)[2][KS], V8 (&vf)[NB]) {
+        const T* kp = reinterpret_cast<const T*>(a.kpool) + ((int64_t)pg * a.Hkv + hk) * (32 * D);
+        const T* kp1 = kp + (nv > 16 ? 16 * D : 0);  // wave-uniform: a scalar base, the lanes' offsets stay what they are
+        const T* vb = reinterpret_cast<const T*>(a.vpool) + ((int64_t)pg * a.Hkv + hk) * (32 * D) + col * 8 +
+                      ((4 * c < nv) ? c * (D * 8) : 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[0][ks] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(kp + lane * 8 + ks * 512));
+            kf[1][ks] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(kp1 + lane * 8 + ks * 512));
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) vf[nb] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(vb + nb * 128));
+    };
     // FULL: every key of the page is visible to every valid column (all but the last page of a decode step) — no
     // masks.  The softmax reference m[ch] is only moved when a tile maximum exceeds it by more than 2^RESCALE_LOG2
     // (then P <= 2^RESCALE_LOG2, harmless in fp32 / f16 / bf16): the rescale of O — whose accumulators live in AGPRs,
@@ -285,7 +306,7 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
         for (; pp < pend; pp += NW) {
             const int pg_next = (pp + NW < pend) ? btrow[pp + NW] : 0;
             V8 kf[2][KS], vf[NB];
-            load_page(pgp, kf, vf);
+            load_page_part(pgp, min(32, ctx - pp * 32), kf, vf);
             apply_page(pp, kf, vf, std::false_type{});
             pgp = pg_next;
         }
