@@ -265,6 +265,56 @@ def test_attention_decode_long_context(nat, gpu_device):
     _close(out.view(B, H, D), want, rtol=2e-3, atol=2e-3, what="long decode attention")
 
 
+@pytest.mark.parametrize("H,Hkv", [(32, 32), (8, 2), (12, 1)])
+def test_attention_decode_every_fill_of_the_last_page(nat, gpu_device, H, Hkv):
+    """Round 5: the page a sequence is filling is requested only up to its last written token (K's second 16-token tile once
+    the sequence has reached it, V's column groups 4 g .. 4 g + 3 up to the last token).  One sequence per fill level
+    1 .. 32, against the oracle — with the regions that must NOT be requested poisoned with NaN after the scatter (an
+    unrequested register never meets an MFMA), and the unwritten slots the kernel MAY still read (the rest of the tile that is
+    being filled, the rest of a started V group) holding large finite garbage that an exact P = 0 has to silence."""
+    dtype, D = torch.float16, 128
+    lens = [64 + nv for nv in range(1, 33)]
+    B = len(lens)
+    g = torch.Generator().manual_seed(77)
+    pages_per = [(l + 31) // 32 for l in lens]
+    total_pages = sum(pages_per)
+    bt = torch.zeros((B, max(pages_per)), dtype=torch.int32)
+    perm = torch.randperm(total_pages, generator=g)
+    o = 0
+    for b in range(B):
+        bt[b, :pages_per[b]] = perm[o:o + pages_per[b]].int()
+        o += pages_per[b]
+    T = sum(lens)
+    kv = torch.randn(T, 2 * Hkv * D, generator=g).to(dtype)
+    dummy = torch.zeros((T, (H + 2 * Hkv) * D), dtype=dtype)
+    dummy[:, H * D:] = kv
+    slots = torch.cat([bt[b, torch.arange(l) // 32].long() * 32 + torch.arange(l) % 32 for b, l in enumerate(lens)]).int()
+    # every slot starts as large finite garbage, the scatter then writes the real tokens
+    kpool = torch.full((total_pages, Hkv, 32 * D), 3.0e4, dtype=dtype, device=gpu_device)
+    vpool = torch.full((total_pages, Hkv, 32 * D), -3.0e4, dtype=dtype, device=gpu_device)
+    nat.rope_kv_write(dummy.to(gpu_device), None, None, None, slots.to(gpu_device), kpool, vpool, H, Hkv, D, D)
+    for b, l in enumerate(lens):
+        nv, pg = l - 64, int(bt[b, 2])
+        if nv <= 16:  # K tile 1 = the second half of the page's [tile][D / 8][16][8] image
+            kpool[pg, :, 16 * D:] = float("nan")
+        vp = vpool[pg].view(Hkv, 4, D, 8)  # V image [4 column groups][D][8]: group g holds tokens 4 g .. 4 g + 3 of both tiles
+        for grp in range(4):
+            if 4 * grp >= nv:
+                vp[:, grp] = float("nan")
+    q = torch.randn(B, H * D, generator=g).to(dtype)
+    cu = [0] + list(np.cumsum(lens))
+    want = ops_ref.attention_varlen(q.view(B, H, D), kv[:, :Hkv * D].view(T, Hkv, D), kv[:, Hkv * D:].view(T, Hkv, D),
+                                    torch.arange(B + 1), cu, D ** -0.5)
+    out = torch.empty((B, H * D), dtype=dtype, device=gpu_device)
+    ns = nat.attn_num_splits(B, Hkv, H, 1, max(lens))
+    ws = nat.Workspace(nat.attn_workspace_bytes(B, H, Hkv, D, ns), gpu_device)
+    nat.attn_paged(q.to(gpu_device), H * D, kpool, vpool, bt.to(gpu_device), torch.tensor(lens, dtype=torch.int32).to(gpu_device),
+                   torch.arange(B + 1, dtype=torch.int32, device=gpu_device), out, B, H, Hkv, D, 1, max(lens), D ** -0.5,
+                   ns, ws)
+    assert torch.isfinite(out).all(), "a region that must not be requested reached an MFMA"
+    _close(out.view(B, H, D), want, rtol=2e-3, atol=2e-3, what="decode attention over every fill of the last page")
+
+
 @pytest.mark.parametrize("dtype,B,H,Hkv,D,ctx", [
     (torch.bfloat16, 16, 32, 4, 64, 512),    # cfg2: GQA 8:1, four key splits
     (torch.float16, 4, 32, 32, 128, 700),    # MHA: four (sequence, head) groups share a 128-byte line of {m, l}
