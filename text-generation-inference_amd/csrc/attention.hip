@@ -31,6 +31,9 @@
 #define ATTN_STAMP(i)
 #define ATTN_STAMP_FLUSH
 #endif
+#ifndef ATTN_BLOCK_REMAP  // tools/floor/attn_unit.hip: which (kv head, sequence) a block id takes, to probe XCD <-> address affinity
+#define ATTN_BLOCK_REMAP(by, bz)
+#endif
 
 namespace {
 
@@ -57,6 +60,7 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     const int col = lane & 15, c = lane >> 4;
     const int qt = blockIdx.x;
     int by = blockIdx.y, bz = blockIdx.z;
+    ATTN_BLOCK_REMAP(by, bz);
     if (a.xcd_remap) {
         // Several blocks per (sequence, split, kv head) group — one per set of 16-head chunks — read the SAME K/V pages.
         // Workgroups go to the 8 XCDs round-robin by linear id, each XCD with its own L2: in grid order the chunk blocks of a

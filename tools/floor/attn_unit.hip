@@ -24,9 +24,14 @@ __device__ long long* g_attn_trace = nullptr;
         for (int i_ = 0; i_ < 8; ++i_) tp_[i_] = st_[i_];                                                                 \
         tp_[8] = xcc_;                                                                                                    \
     }
+// ATTN_ROT=r: block (y, z) takes kv head (y + r) % gridDim.y — workgroups go to XCD (y + gridDim.y z) % 8, so r rotates which XCD
+// reads which heads' 8 KiB slices of every page (are some XCD <-> address pairs closer than others?)
+__device__ int g_attn_head_rot = 0;
+#define ATTN_BLOCK_REMAP(by, bz) do { by = (by + g_attn_head_rot) % (int)gridDim.y; } while (0)
 #include "attention.hip"
 
 #include <algorithm>
+#include <cstring>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -42,8 +47,12 @@ static void run(const char* name, int B, int H, int Hkv, int D, int ctx, int dty
         CK(hipMemset(kp[i], 0x3c, pool_bytes)); CK(hipMemset(vp[i], 0x3c, pool_bytes));
     }
     std::vector<int32_t> bt(total), ctxl(B, ctx), cu(B + 1);
-    for (int i = 0; i < total; ++i) bt[i] = i;
-    for (int i = total - 1; i > 0; --i) std::swap(bt[i], bt[rnd() % (i + 1)]);
+    if (getenv("ATTN_ORDER") && !strcmp(getenv("ATTN_ORDER"), "page-major")) {   // the product's pool since round 5: page p of every sequence side by side
+        for (int b = 0; b < B; ++b) for (int p = 0; p < pages_per; ++p) bt[b * pages_per + p] = p * B + b;
+    } else {                                                                        // rounds 1-4: a fixed pseudo-random order
+        for (int i = 0; i < total; ++i) bt[i] = i;
+        for (int i = total - 1; i > 0; --i) std::swap(bt[i], bt[rnd() % (i + 1)]);
+    }
     for (int i = 0; i <= B; ++i) cu[i] = i;
     int32_t *dbt, *dctx, *dcu;
     CK(hipMalloc(&dbt, total * 4)); CK(hipMalloc(&dctx, B * 4)); CK(hipMalloc(&dcu, (B + 1) * 4));
@@ -149,6 +158,14 @@ static void run(const char* name, int B, int H, int Hkv, int D, int ctx, int dty
 }
 
 int main(int argc, char** argv) {
+    if (getenv("ATTN_ROT_SWEEP")) {   // cfg3 shape only, every rotation of the head <-> XCD assignment
+        for (int r = 0; r < 8; ++r) {
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_head_rot), &r, sizeof(r)));
+            char name[64]; snprintf(name, sizeof(name), "cfg3 MHA, heads rotated by %d", r);
+            run(name, 32, 32, 32, 128, 1023, TGIS_F16, 0);
+        }
+        return 0;
+    }
     run("cfg3 MHA", 32, 32, 32, 128, 1023, TGIS_F16, 0);
     run("cfg3 MHA (again)", 32, 32, 32, 128, 1023, TGIS_F16, 0);
     run("cfg3 MHA (ctx 1024)", 32, 32, 32, 128, 1024, TGIS_F16, 0);
