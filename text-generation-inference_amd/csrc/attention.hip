@@ -214,14 +214,15 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) vf[nb] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(vb + nb * 128));
     };
-    // The page a sequence is still filling: only the cache lines of its nv written tokens are requested (round 5: the launch
+    // The page a sequence is still filling: only the part its nv written tokens occupy is requested (round 5: the launch
     // cost one whole page per started page — bench.py's steps got 0.1 ms slower the moment the batch crossed a page
-    // boundary, and the counters saw 1.016 x the algorithmic bytes).  K interleaves a tile's 16 tokens at 16 bytes (a lane is
-    // one token), V keeps tokens 4 g .. 4 g + 3 of both tiles in column group g (a lane is one group): the lanes of unwritten
-    // tile is not requested while the sequence fills the first one (its registers repeat the first tile: finite values whose
-    // scores are masked), the lanes of unwritten V groups re-read group 0 (lines the wave requests anyway; their P is exactly
-    // 0) — addresses move, no lane is switched off.  (Redirecting the unwritten tokens of the tile that IS being filled as
-    // well costs 6 - 9 more VGPRs, i.e. the third wave per SIMD that the many-block shapes need; not done.)
+    // boundary, and the counters saw 1.016 x the algorithmic bytes).  K: the second 16-token tile is requested only once the
+    // sequence has reached it — until then its registers repeat the first tile (finite values, scores masked); a scalar base,
+    // the lanes' offsets stay what they are.  V keeps tokens 4 g .. 4 g + 3 of both tiles in column group g and a lane reads one
+    // group: the lanes of groups behind the last written token re-read group 0 (lines the wave requests anyway; finite values
+    // under a P of exactly 0).  Addresses move, no lane is switched off.  (Redirecting the unwritten tokens INSIDE the tile that
+    // is being filled as well costs 6 - 9 more VGPRs — two instead of three waves per SIMD, which the many-block shapes need;
+    // tests/test_ops_gpu.py::test_attention_decode_every_fill_of_the_last_page poisons what must not be requested.)
     auto load_page_part = [&](const int pg, const int nv, V8 (&kf)[2][KS], V8 (&vf)[NB]) {
         const T* kp = reinterpret_cast<const T*>(a.kpool) + ((int64_t)pg * a.Hkv + hk) * (32 * D);
         const T* kp1 = kp + (nv > 16 ? 16 * D : 0);  // wave-uniform: a scalar base, the lanes' offsets stay what they are
