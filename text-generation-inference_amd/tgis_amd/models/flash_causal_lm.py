@@ -88,7 +88,7 @@ class FlashCausalLMBatch(Batch):
         # page-major: page p of every sequence, then page p + 1 (kv_cache.py: the pages the decode blocks read at the same
         # time are then neighbours in the pool)
         self.pages, it = [[] for _ in need], iter(flat)
-        g = int(os.getenv("TGIS_KV_PAGE_GROUP", "0")) or len(need)
+        g = max(1, int(os.getenv("TGIS_KV_PAGE_GROUP", "0")) or len(need))  # sequences per page-major group (default: all)
         for g0 in range(0, len(need), g):
             grp = range(g0, min(g0 + g, len(need)))
             for p in range(max((need[i] for i in grp), default=0)):
