@@ -255,10 +255,7 @@ def bench_causal_lm_cpu(args):
     out = {"metric": f"decode tokens/sec (GPT-2 small fp32 CPU causal_lm, batch {B}) + p50 step latency",
            "value": round(B * K / elapsed, 2), "unit": "tokens/s", "n_gpus": 0, "steps": K, "warmup": W,
            "ms_per_step": round(elapsed / K * 1e3, 4),
-        # timed blocks of `steps` steps each (fresh batch, same shape); ms_per_step / value are the median block
-        "timed_blocks": len(block_ms_per_step), "ms_per_step_blocks": block_ms_per_step,
-        "ms_per_step_range": [min(block_ms_per_step), max(block_ms_per_step)],
-        "p50_step_ms": round(sorted(step_ms)[len(step_ms) // 2], 4),
+           "p50_step_ms": round(sorted(step_ms)[len(step_ms) // 2], 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic (seeded random-init GPT-2 small, seeded token ids)",
            "config": {"workload": f"gpt2-small fp32 CPU causal_lm (padded batch), B={B}, L_in={L_in}, prefill + {W} warm-up + "
@@ -282,6 +279,109 @@ def bench_causal_lm_cpu(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_churn(args, lm, tok, B, ctx_mean, make_batch_pb):
+    """the decode path under the membership changes the reference's servicer makes between steps
+    (server.py:183-231 -> flash_causal_lm.py:196-353 concatenate / prune; router side batcher.rs:497-518).  Same weights and
+    kernels as the headline line; every 4-8 decode steps 1-2 requests complete (prune) and 0-2 new ones are prefilled and
+    concatenated, the batch wandering in [3B/4, B].  The same seeded schedule runs on (A) a pristine pool, (B) a pool aged by
+    random allocations and frees, (C) the aged pool under the round-5 free list (one residue class) and (D) the aged pool with
+    a decode graph captured per exact batch size instead of per bucket.  Reported per run: p50 / p99 / mean of the host time
+    of the decode steps (generate_token incl. the copy of the ids), tokens/s, graph captures and what each cost."""
+    import random
+
+    import tgis_amd.models.flash_causal_lm as fcl
+
+    cache = lm.kv_cache
+    C0 = cache.classes
+    lo_b = max(1, 3 * B // 4)
+    steps = args.churn_steps
+    max_new = 256
+
+    def age_pool(seed):
+        rng = random.Random(seed)
+        held = []
+        while cache.free_pages > cache.num_pages // 4:
+            held.append(cache.alloc(rng.randrange(1, 48)))
+        rng.shuffle(held)
+        while cache.free_pages < cache.num_pages // 2:
+            cache.free(held.pop())
+        return held
+
+    def prefill(n, rng, first_id, batch_id):
+        lens = [rng.randrange(max(1, ctx_mean - 192), max(2, ctx_mean - 32)) for _ in range(n)]
+        pb = make_batch_pb(lens, max_new=max_new, first_request_id=first_id, batch_id=batch_id)
+        b, errs = lm.batch_type.from_pb(pb, tok, lm.dtype, lm.device, lm.word_embeddings, None, True)
+        assert not errs
+        lm.generate_token(b, first=True, for_concat=True)
+        return b
+
+    def run(name, aged, classes, buckets):
+        cache.reset_free_lists(classes)
+        held = age_pool(11) if aged else []
+        fcl.GRAPH_BUCKETS = buckets
+        lm._graphs.clear()
+        lm.graph_captures.clear()
+        lm.graph_pool = torch.cuda.graph_pool_handle()
+        rng = random.Random(1234)
+        with lm.context_manager():
+            batch = prefill(B, rng, 0, 0)
+            next_id, next_event = B, rng.randrange(4, 9)
+            step_ms, sizes, ctxs, member_ms = [], [], [], []
+            for s in range(steps):
+                if s == next_event:
+                    t0 = time.perf_counter()
+                    ids = [r.id for r in batch.requests]
+                    n_done = min(rng.randrange(1, 3), len(ids) - 1)
+                    batch = lm.batch_type.prune(batch, rng.sample(ids, n_done))
+                    n_new = rng.randrange(0, 3)
+                    n_new = max(n_new, lo_b - len(batch))
+                    n_new = min(n_new, B - len(batch))
+                    if n_new > 0:
+                        nb = prefill(n_new, rng, next_id, 1 + s)
+                        next_id += n_new
+                        batch = lm.batch_type.concatenate([batch, nb])
+                    torch.cuda.synchronize()
+                    member_ms.append((time.perf_counter() - t0) * 1e3)
+                    next_event = s + rng.randrange(4, 9)
+                t0 = time.perf_counter()
+                lm.generate_token(batch)
+                step_ms.append((time.perf_counter() - t0) * 1e3)
+                sizes.append(len(batch))
+                ctxs.append(sum(batch.input_lengths) / len(batch))
+            torch.cuda.synchronize()
+            batch.release()
+        for h in held:
+            cache.free(h)
+        caps = list(lm.graph_captures)
+        srt = sorted(step_ms)
+        # steps that captured a graph are reported separately AND are part of p99 / mean: a serving step pays them
+        return {"run": name, "pool": "aged" if aged else "pristine", "page_classes": classes,
+                "graph_rows": "bucket" if buckets else "exact batch size", "decode_steps": steps,
+                "p50_ms": round(srt[len(srt) // 2], 4), "p99_ms": round(srt[min(len(srt) - 1, int(len(srt) * 0.99))], 4),
+                "mean_ms": round(sum(step_ms) / len(step_ms), 4), "max_ms": round(srt[-1], 3),
+                "tokens_per_s": round(sum(sizes) / (sum(step_ms) * 1e-3), 1),
+                "mean_batch": round(sum(sizes) / len(sizes), 2), "mean_ctx": round(sum(ctxs) / len(ctxs), 1),
+                "membership_events": len(member_ms),
+                "membership_ms_mean": round(sum(member_ms) / max(len(member_ms), 1), 2),
+                "graph_captures": len(caps), "graph_capture_ms": [round(c[2], 1) for c in caps],
+                "graph_keys": sorted({(c[0], c[1]) for c in caps})}
+
+    runs = [run("A", False, C0, True), run("B", True, C0, True), run("C", True, 1, True), run("D", True, C0, False)]
+    cache.reset_free_lists(C0)
+    fcl.GRAPH_BUCKETS = True
+    a, b, c, d = runs
+    out = {"metric": f"decode ms/step under batch churn ({args.config}, B in [{lo_b}, {B}], ctx ~{ctx_mean})",
+           "unit": "ms", "higher_is_better": False, "n_gpus": 1, "data": "synthetic",
+           "config": {"workload": f"{args.config} decode under churn: {steps} decode steps, a prune + 0-2 request Prefill + "
+                                  f"concatenate every 4-8 steps, seeded schedule, greedy", "pool_pages": cache.num_pages,
+                      "page_bytes": cache.num_kv_heads * 32 * cache.head_dim * 2, "default_page_classes": C0},
+           "runs": runs,
+           "aged_over_pristine_p50": round(b["p50_ms"] / a["p50_ms"], 4),
+           "one_class_over_classes_p50": round(c["p50_ms"] / b["p50_ms"], 4),
+           "p99_over_p50": {r["run"]: round(r["p99_ms"] / r["p50_ms"], 3) for r in runs}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -292,6 +392,11 @@ def main():
     ap.add_argument("--ctx", type=int, default=None, help="mean context length over the timed steps")
     ap.add_argument("--blocks", type=int, default=3, help="timed blocks of --steps steps each; the median block is reported")
     ap.add_argument("--dump-steps", action="store_true", help="stderr: the host-side time of every timed step, per block")
+    ap.add_argument("--churn", action="store_true",
+                    help="the path the way the router drives it: requests leave (prune) and join (Prefill + concatenate) every "
+                         "4-8 steps, B wandering in [3B/4, B], on a pristine and on an aged page pool; prints ONE JSON line of "
+                         "its own (p50 / p99 of the decode steps, graph captures) — not the driver's contract line")
+    ap.add_argument("--churn-steps", type=int, default=240)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -355,6 +460,8 @@ def main():
     eng = InferenceEngine(tensors, cfg, dtype, quantize, tokenizer=tok)
     del tensors
     pages = B * PagedKVCache.pages_for(total_len) + 8
+    if args.churn:
+        pages = 4 * B * PagedKVCache.pages_for(ctx_mean + 256) + 64  # room for an aged pool's holes
     lm = FlashCausalLM("synthetic", None, "synthetic", dtype, quantize, engine=eng, kv_cache_pages=pages)
     torch.cuda.empty_cache()
     tp = eng.world_size
@@ -373,6 +480,10 @@ def main():
         return batch
 
     from tgis_amd.utils import graph_segments
+
+    if args.churn:
+        assert tp == 1, "--churn is a single-GPU measurement"
+        return bench_churn(args, lm, tok, B, ctx_mean, make_batch_pb)
 
     with lm.context_manager():
         # Three timed blocks of exactly K steps each, every one on a fresh batch of the same shape (prefill + W warm-up

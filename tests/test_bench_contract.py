@@ -54,3 +54,19 @@ def test_round5_bench_line_reports_the_median_of_three_timed_blocks():
     for k in ("roofline", "cpu_baseline", "step_roofline"):
         assert k in d, k
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+
+
+def test_gpt2_cpu_bench_leg_runs_and_prints_the_contract_line():
+    """BASELINE config 1 (`bench.py --config gpt2-cpu`, the README's command) prints one JSON line; round 5 shipped it with a
+    NameError that no test saw."""
+    import subprocess
+    import sys
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "gpt2-cpu", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 0 and d["dtype"] == "f32" and d["steps"] == 1 and d["value"] > 0

@@ -543,3 +543,56 @@ def test_pages_grow_with_the_tokens_and_the_memory_model_is_measured(gpu_device)
     assert pb.weight_limit == (lm.kv_cache.num_pages - 4) * 32 * 80 // 100 and pb.nexttoken_linear_coef1 == 1.0
     assert pb.prefill_linear_coef0 >= 1.0
     assert lm.kv_cache.free_pages == lm.kv_cache.num_pages, "the probes gave their pages back"
+
+
+def test_decode_graph_buckets_match_exact_size_graphs(gpu_device, monkeypatch):
+    """Round 6: a captured decode step serves every batch size of its bucket — the rows past the batch
+    are inactive (position 0 on the pool's null page).  The active rows' logits, ids and logprobs must be bit-identical to
+    the graph captured at the exact batch size, through a prune that changes the bucket and a batch that shrinks inside one;
+    the inactive rows may write the null page and nothing else."""
+    import tgis_amd.models.flash_causal_lm as fcl
+
+    cfg = TinyLlamaConfig()
+    tensors = tiny_llama_tensors(cfg, seed=5, quantize="gptq", groupsize=64)
+    rng = np.random.default_rng(3)
+    prompts = [rng.integers(3, cfg.vocab_size, size=n).tolist() for n in (9, 33, 64, 5, 47)]
+
+    def run(buckets):
+        monkeypatch.setattr(fcl, "GRAPH_BUCKETS", buckets)
+        lm, tok = _build(cfg, tensors, "gptq", 64, torch.float16)
+        tap = _LogitTap(lm)
+        batch = _from_pb(lm, tok, _pb(prompts, 12))
+        seen = set()
+
+        def step(first=False):
+            r = _step(lm, batch, tap, first=first)
+            seen.update(pg for p in batch.pages for pg in p)
+            return r
+
+        out = [step(first=True)]
+        out += [step() for _ in range(3)]                          # 5 rows: bucket 8
+        with lm.context_manager():
+            batch = lm.batch_type.prune(batch, [1])
+        out += [step() for _ in range(2)]                          # 4 rows: bucket 4
+        with lm.context_manager():
+            batch = lm.batch_type.prune(batch, [3])
+        out += [step() for _ in range(2)]                          # 3 rows: still bucket 4, one row inactive again
+        keys = sorted(lm._graphs)
+        pool = lm.kv_cache.pool
+        never = [p for p in range(lm.kv_cache.num_pages) if p not in seen]
+        untouched = bool((pool[:, :, never] == 0).all())
+        null_written = bool((pool[:, :, lm.kv_cache.null_page] != 0).any())
+        batch.release()
+        assert lm.kv_cache.free_pages == lm.kv_cache.num_pages
+        return out, keys, untouched, null_written
+
+    got_b, keys_b, untouched, null_written = run(True)
+    got_e, keys_e, untouched_e, null_e = run(False)
+    assert untouched_e
+    assert [k[0] for k in keys_b] == [4, 8] and [k[0] for k in keys_e] == [3, 4, 5]
+    assert null_written and not null_e, "inactive rows write the null page; exact-size graphs have none"
+    assert untouched, "a page no sequence ever owned was written"
+    for i, ((tb, lb), (te, le)) in enumerate(zip(got_b, got_e)):
+        assert [t.token_id for t in tb] == [t.token_id for t in te], f"step {i}: ids"
+        assert [t.logprob for t in tb] == [t.logprob for t in te], f"step {i}: logprobs"
+        assert np.array_equal(lb, le), f"step {i}: logits differ between the bucket graph and the exact-size graph"

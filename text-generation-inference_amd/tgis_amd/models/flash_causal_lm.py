@@ -68,6 +68,7 @@ class FlashCausalLMBatch(Batch):
     # paged-KV ownership: page ids per request, filled by the prefill generate_token
     kv_cache: Optional[PagedKVCache] = None
     pages: Optional[List[List[int]]] = None
+    lanes: Optional[List[int]] = None  # kv_cache.py: which residue class of the pool page p of a sequence comes from
     block_tables: Optional[torch.Tensor] = None
 
     def get_id(self) -> int:
@@ -83,18 +84,16 @@ class FlashCausalLMBatch(Batch):
         batch-weight model (router/src/batch_types.rs:46-118) counts tokens present, not max_output_length."""
         assert self.pages is None
         need = [PagedKVCache.pages_for(n + 1) for n in self.input_lengths]
-        flat = kv_cache.alloc(sum(need))  # raises OutOfPages before anything is taken
-        self.kv_cache = kv_cache
-        # page-major: page p of every sequence, then page p + 1 (kv_cache.py: the pages the decode blocks read at the same
-        # time are then neighbours in the pool)
-        self.pages, it = [[] for _ in need], iter(flat)
-        g = max(1, int(os.getenv("TGIS_KV_PAGE_GROUP", "0")) or len(need))  # sequences per page-major group (default: all)
-        for g0 in range(0, len(need), g):
-            grp = range(g0, min(g0 + g, len(need)))
-            for p in range(max((need[i] for i in grp), default=0)):
-                for i in grp:
-                    if p < need[i]:
-                        self.pages[i].append(next(it))
+        lanes = kv_cache.new_lanes(len(need))
+        # page-major: page p of every sequence, then page p + 1; page p of the sequence in lane l comes from residue class
+        # l + p of the pool (kv_cache.py: the pages the decode blocks read at the same time are a dense run of a pristine
+        # pool and cover the classes evenly in a churned one).  One all-or-nothing request: OutOfPages before anything is taken.
+        order = [(p, i) for p in range(max(need, default=0)) for i in range(len(need)) if p < need[i]]
+        flat = kv_cache.alloc_classes([lanes[i] + p for p, i in order])
+        self.kv_cache, self.lanes = kv_cache, lanes
+        self.pages = [[] for _ in need]
+        for (p, i), pg in zip(order, flat):
+            self.pages[i].append(pg)
         self._rebuild_block_tables()
 
     def grow_pages(self):
@@ -102,7 +101,8 @@ class FlashCausalLMBatch(Batch):
         short = [i for i, (p, n) in enumerate(zip(self.pages, self.input_lengths)) if len(p) * PAGE < n]
         if not short:
             return
-        flat = self.kv_cache.alloc(len(short))  # all or nothing: OutOfPages leaves the batch as it was
+        # all or nothing: OutOfPages leaves the batch as it was
+        flat = self.kv_cache.alloc_classes([self.lanes[i] + len(self.pages[i]) for i in short])
         for i, pg in zip(short, flat):
             self.pages[i].append(pg)
         width = self.block_tables.shape[1]
@@ -128,7 +128,8 @@ class FlashCausalLMBatch(Batch):
         if self.pages is not None and self.kv_cache is not None:
             for p in self.pages:
                 self.kv_cache.free(p)
-        self.pages = None
+            self.kv_cache.drop_lanes(self.lanes or [])
+        self.pages = self.lanes = None
         self.block_tables = None
 
     def __del__(self):
@@ -214,7 +215,7 @@ class FlashCausalLMBatch(Batch):
     def concatenate(cls, batches: List["FlashCausalLMBatch"]) -> "FlashCausalLMBatch":
         first = batches[0]
         device = first.cu_seqlens_q.device
-        requests, input_lengths, total_lengths, pages = [], [], [], []
+        requests, input_lengths, total_lengths, pages, lanes = [], [], [], [], []
         chooser_params, ntc_current_tokens, ntc_samplings, ntc_return_logprobs = [], [], [], []
         input_ids, position_ids = [], []
         cu_seqlens = [torch.tensor([0], dtype=torch.int32, device=device)]
@@ -238,6 +239,7 @@ class FlashCausalLMBatch(Batch):
             # no KV bytes move (reference: torch.cat of the pasts); ownership of the pages changes hands below, once
             # the merged batch exists — an exception before that leaves every page with its source batch
             pages.extend(batch.pages)
+            lanes.extend(batch.lanes)
             end = start + len(batch)
             all_input_ids_tensor[start:end, :batch.all_input_ids_tensor.shape[1]] = batch.all_input_ids_tensor
             start = end
@@ -258,14 +260,14 @@ class FlashCausalLMBatch(Batch):
             total_lengths=total_lengths, all_input_ids_tensor=all_input_ids_tensor,
             next_token_chooser=next_token_chooser, pad_token_id=first.pad_token_id,
             kv_cache=first.kv_cache, pages=None)
-        merged.pages = pages
+        merged.pages, merged.lanes = pages, lanes
         try:
             merged._rebuild_block_tables()
         except BaseException:
-            merged.pages = None  # the sources still own them
+            merged.pages = merged.lanes = None  # the sources still own them
             raise
         for batch in batches:
-            batch.pages = None
+            batch.pages = batch.lanes = None
             batch.block_tables = None
         return merged
 
@@ -283,8 +285,10 @@ class FlashCausalLMBatch(Batch):
         for i, p in enumerate(batch.pages):
             if i not in keep:
                 batch.kv_cache.free(p)
+                batch.kv_cache.drop_lanes(batch.lanes[i:i + 1])
         pick = (lambda l: [l[i] for i in keep_indices])
         batch.pages = pick(batch.pages)
+        batch.lanes = pick(batch.lanes)
         batch.input_lengths = pick(batch.input_lengths)
         batch.total_lengths = pick(batch.total_lengths)
         batch.requests = pick(batch.requests)
@@ -310,14 +314,33 @@ class FlashCausalLMBatch(Batch):
 FRESH_PREFILL_KV = os.getenv("TGIS_PREFILL_KV", "true").lower() not in ("0", "false")
 
 
+# A captured decode step serves every batch size of its BUCKET (round 6): the rows past the batch are inactive — position 0,
+# every table entry the pool's null page (utils/kv_cache.py), their token written there and attended to alone, their ids
+# never read.  A router that lets a batch wander over 24..32 requests then replays ONE graph instead of capturing nine (a
+# capture is a warm-up step + the capture itself: tens of ms in the middle of serving; bench.py --churn reports them).
+GRAPH_BUCKETS = os.getenv("TGIS_GRAPH_BUCKETS", "true").lower() not in ("0", "false")
+
+
+def graph_bucket(B: int) -> int:
+    """Rows of the decode graph that serves B requests: powers of two up to 8, then multiples of 8 (the GEMMs cost the same
+    up to 32 rows and from 33 to 64; an inactive row costs the attention one page)."""
+    if not GRAPH_BUCKETS:
+        return B
+    if B <= 8:
+        return 1 << (B - 1).bit_length()
+    return (B + 7) // 8 * 8
+
+
 class _DecodeGraph:
-    """Static buffers + captured HIP graph of one decode step for a (batch size, table width) pair."""
+    """Static buffers + captured HIP graph of one decode step for a (batch-size bucket, table width) pair."""
 
     def __init__(self, lm: "FlashCausalLM", B: int, width: int):
         dev = lm.device
+        self.rows = B
+        self.active = 0  # rows [0, active) hold a batch's sequences, the rest are inactive
         self.input_ids = torch.zeros(B, dtype=torch.int64, device=dev)
         self.positions = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.block_tables = torch.zeros((B, width), dtype=torch.int32, device=dev)
+        self.block_tables = torch.full((B, width), lm.kv_cache.null_page, dtype=torch.int32, device=dev)
         self.slots = torch.zeros(B, dtype=torch.int32, device=dev)
         self.ctx = torch.ones(B, dtype=torch.int32, device=dev)
         self.cu_q = torch.arange(B + 1, dtype=torch.int32, device=dev)
@@ -359,16 +382,28 @@ class _DecodeGraph:
         return logits, ids, lps
 
     def run(self, input_ids, position_ids, block_tables):
+        """One decode step of a batch of n <= rows sequences; returns (logits, ids, logprobs) of its n rows."""
+        n = input_ids.numel()
+        if n < self.active:  # rows a larger batch used before: inactive again
+            self.positions[n:self.active].zero_()
+            self.input_ids[n:self.active].zero_()
+            self.block_tables[n:self.active].fill_(self.lm.kv_cache.null_page)
+        self.active = n
         if input_ids is not self.staged_ids or position_ids is not self.staged_pos:
-            self.input_ids.copy_(input_ids, non_blocking=True)
-            self.positions.copy_(position_ids, non_blocking=True)
+            self.input_ids[:n].copy_(input_ids, non_blocking=True)
+            self.positions[:n].copy_(position_ids, non_blocking=True)
         if block_tables is not self.staged_bt:
-            self.block_tables.copy_(block_tables, non_blocking=True)
+            self.block_tables[:n].copy_(block_tables, non_blocking=True)
             self.staged_bt = block_tables
         self.staged_ids = self.staged_pos = None
+        logits, ids, lps = self._run()
+        return (logits, ids, lps) if n == self.rows else (logits[:n], ids[:n], lps[:n])
+
+    def _run(self):
         if not self.lm.use_graphs:
             return self._step()
         if self.graph is None:
+            t_capture = time.perf_counter()
             # warm-up: sizes the workspaces, builds rope tables and (tp > 1) initialises the RCCL communicators outside
             # the capture
             self._step()
@@ -407,6 +442,8 @@ class _DecodeGraph:
                     self.lm.use_graphs = False
                     return self._step()
             self.graph = g
+            # (rows, table width, host ms of warm-up step + capture): what a new (bucket, width) pair costs a serving step
+            self.lm.graph_captures.append((self.rows, self.block_tables.shape[1], (time.perf_counter() - t_capture) * 1e3))
         self.graph.replay()
         return self.logits, self.ids, self.logprobs
 
@@ -485,6 +522,7 @@ class FlashCausalLM(Model):
         # captured decode steps, least recently used first; they share one memory pool (a step's intermediates are dead
         # once it has run, and its outputs are consumed before the next replay), and the number kept is bounded
         self._graphs = OrderedDict()
+        self.graph_captures: List[Tuple[int, int, float]] = []
         self.max_graphs = int(os.getenv("TGIS_MAX_DECODE_GRAPHS", "48"))
         self.graph_pool = torch.cuda.graph_pool_handle() if self.use_graphs else None
 
@@ -598,7 +636,7 @@ class FlashCausalLM(Model):
 
     def _decode_forward(self, batch: FlashCausalLMBatch):
         batch.grow_pages()
-        key = (len(batch), batch.block_tables.shape[1])
+        key = (graph_bucket(len(batch)), batch.block_tables.shape[1])
         g = self._graphs.get(key)
         if g is None:
             while len(self._graphs) >= self.max_graphs:
@@ -662,8 +700,8 @@ class FlashCausalLM(Model):
             # buffers of the graph that will run it
             next_token_ids = native.decode_advance(
                 next_token_ids, batch.position_ids, batch.all_input_ids_tensor, batch.cu_seqlens, batch.cu_seqlens_q,
-                stage_ids=graph.input_ids if graph is not None else None,
-                stage_positions=graph.positions if graph is not None else None)
+                stage_ids=graph.input_ids[:len(batch)] if graph is not None else None,
+                stage_positions=graph.positions[:len(batch)] if graph is not None else None)
             if graph is not None:
                 graph.staged_ids, graph.staged_pos = next_token_ids, batch.position_ids
 

@@ -116,7 +116,60 @@ def more_rounds(B=64, H=32, Hkv=32, D=128, ctx=1023, sets=4):
             print(f"  {name:42s} {t:7.2f} us   {B * ctx * 2 * Hkv * D * 2 / t / 1e6:6.2f} TB/s")
 
 
+def aged_tables(C, B, P, cap, seed=0):
+    """Block tables [B, P] the product's allocator (utils/kv_cache.py, C residue classes) hands a batch on a pool of `cap`
+    pages that has churned: random allocations and frees first, half of what is held then freed."""
+    import random
+
+    from tgis_amd.utils.kv_cache import PagedKVCache
+
+    rng = random.Random(seed)
+    cache = PagedKVCache(1, 1, 8, cap, torch.float16, torch.device("cpu"), classes=C)
+    held = []
+    while cache.free_pages > cap // 4:
+        held.append(cache.alloc(rng.randrange(1, 48)))
+    rng.shuffle(held)
+    while cache.free_pages < B * P + cap // 8:
+        cache.free(held.pop())
+    lanes = cache.new_lanes(B)
+    flat = cache.alloc_classes([lanes[b] + p for p in range(P) for b in range(B)])
+    return torch.tensor(flat, dtype=torch.int32).view(P, B).t().contiguous()
+
+
+def classes_sweep(B=32, H=32, Hkv=32, D=128, ctx=1023, sets=4):
+    """Round 6: how many residue classes does the free list need so that a churned pool reads like a pristine one?"""
+    P = (ctx + 31) // 32
+    total = B * P
+    cap = 4 * total
+    pools = [(torch.randn(cap, Hkv, 32 * D, device=dev).half(), torch.randn(cap, Hkv, 32 * D, device=dev).half())
+             for _ in range(sets)]
+    q = torch.randn(B, H * D, device=dev).half()
+    ctxl = torch.full((B,), ctx, dtype=torch.int32, device=dev)
+    cu = torch.arange(B + 1, dtype=torch.int32, device=dev)
+    out = torch.empty(B, H * D, device=dev, dtype=torch.float16)
+    ns = nat.attn_num_splits(B, Hkv, H, 1, ctx)
+    ws = nat.Workspace(nat.attn_workspace_bytes(B, H, Hkv, D, ns), dev)
+    orders = {"page-major p*B+b (pristine)": torch.arange(total).int().view(P, B).t().contiguous(),
+              "random over the 4x pool": torch.randperm(cap)[:total].int().view(B, P).contiguous()}
+    for C in (1, 2, 4, 8, 16, 32, 64, 128):
+        orders[f"churned pool, {C:3d} classes"] = aged_tables(C, B, P, cap)
+    print(f" B {B} H {H} Hkv {Hkv} D {D} ctx {ctx} splits {ns} page {Hkv * 32 * D * 2 // 1024} KiB")
+    for rnd in range(2):
+        for name, bt in orders.items():
+            bt = bt.to(dev)
+            t = timeit(lambda i: nat.attn_paged(q, H * D, pools[i % sets][0], pools[i % sets][1], bt, ctxl, cu, out, B, H, Hkv, D, 1,
+                                                ctx, D ** -0.5, ns, ws), iters=40)
+            print(f"  {name:34s} {t:7.2f} us   {B * ctx * 2 * Hkv * D * 2 / t / 1e6:6.2f} TB/s")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "classes":
+        classes_sweep()                                  # cfg3: 256 KiB pages
+        classes_sweep(H=4, Hkv=4)                        # a cfg3 rank at TP 8: 32 KiB pages
+        classes_sweep(B=64, H=64, Hkv=8, ctx=2047, sets=2)   # cfg4 on one GPU: 64 KiB pages
+        classes_sweep(B=16, H=32, Hkv=4, D=64, ctx=511)  # cfg2: 16 KiB pages
+        classes_sweep(B=32, H=48, Hkv=1, ctx=4095)       # cfg5: 8 KiB pages
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "rounds":
         more_rounds(B=32)                            # cfg3
         more_rounds(B=64)                            # cfg3 at B = 64: two rounds of blocks
