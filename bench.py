@@ -284,24 +284,24 @@ def bench_churn(args, lm, tok, B, ctx_mean, make_batch_pb):
     (server.py:183-231 -> flash_causal_lm.py:196-353 concatenate / prune; router side batcher.rs:497-518).  Same weights and
     kernels as the headline line; every 4-8 decode steps 1-2 requests complete (prune) and 0-2 new ones are prefilled and
     concatenated, the batch wandering in [3B/4, B].  The same seeded schedule runs on (A) a pristine pool, (B) a pool aged by
-    random allocations and frees, (C) the aged pool under the round-5 free list (one residue class) and (D) the aged pool with
-    a decode graph captured per exact batch size instead of per bucket.  Reported per run: p50 / p99 / mean of the host time
+    random allocations and frees (B2: in pieces of one or two pages, the finest fragmentation) and (C) the aged pool with a decode graph captured per exact batch size instead of per
+    bucket.  (Round 6 also ran the aged pool under a channel-aware free list, one heap per page-id residue class: p50 4.149 vs
+    4.144 ms for this allocator — profiles/r06a_churn_cfg3_classes.json, r06_page_classes.log; not kept.)  Reported per run: p50 / p99 / mean of the host time
     of the decode steps (generate_token incl. the copy of the ids), tokens/s, graph captures and what each cost."""
     import random
 
     import tgis_amd.models.flash_causal_lm as fcl
 
     cache = lm.kv_cache
-    C0 = cache.classes
     lo_b = max(1, 3 * B // 4)
     steps = args.churn_steps
     max_new = 256
 
-    def age_pool(seed):
+    def age_pool(seed, largest):
         rng = random.Random(seed)
         held = []
         while cache.free_pages > cache.num_pages // 4:
-            held.append(cache.alloc(rng.randrange(1, 48)))
+            held.append(cache.alloc(rng.randrange(1, largest + 1)))
         rng.shuffle(held)
         while cache.free_pages < cache.num_pages // 2:
             cache.free(held.pop())
@@ -315,9 +315,11 @@ def bench_churn(args, lm, tok, B, ctx_mean, make_batch_pb):
         lm.generate_token(b, first=True, for_concat=True)
         return b
 
-    def run(name, aged, classes, buckets):
-        cache.reset_free_lists(classes)
-        held = age_pool(11) if aged else []
+    def run(name, aged, buckets):
+        # aged = largest piece of the random allocations that fragment the pool (48: holes of up to a sequence's worth of
+        # pages; 2: holes of one or two pages — the finest fragmentation a pool can have), 0 = pristine
+        assert cache.free_pages == cache.num_pages
+        held = age_pool(11, aged) if aged else []
         fcl.GRAPH_BUCKETS = buckets
         lm._graphs.clear()
         lm.graph_captures.clear()
@@ -355,7 +357,7 @@ def bench_churn(args, lm, tok, B, ctx_mean, make_batch_pb):
         caps = list(lm.graph_captures)
         srt = sorted(step_ms)
         # steps that captured a graph are reported separately AND are part of p99 / mean: a serving step pays them
-        return {"run": name, "pool": "aged" if aged else "pristine", "page_classes": classes,
+        return {"run": name, "pool": f"aged (pieces of 1-{aged} pages)" if aged else "pristine",
                 "graph_rows": "bucket" if buckets else "exact batch size", "decode_steps": steps,
                 "p50_ms": round(srt[len(srt) // 2], 4), "p99_ms": round(srt[min(len(srt) - 1, int(len(srt) * 0.99))], 4),
                 "mean_ms": round(sum(step_ms) / len(step_ms), 4), "max_ms": round(srt[-1], 3),
@@ -366,18 +368,17 @@ def bench_churn(args, lm, tok, B, ctx_mean, make_batch_pb):
                 "graph_captures": len(caps), "graph_capture_ms": [round(c[2], 1) for c in caps],
                 "graph_keys": sorted({(c[0], c[1]) for c in caps})}
 
-    runs = [run("A", False, C0, True), run("B", True, C0, True), run("C", True, 1, True), run("D", True, C0, False)]
-    cache.reset_free_lists(C0)
+    runs = [run("A", 0, True), run("B", 48, True), run("B2", 2, True), run("C", 48, False)]
     fcl.GRAPH_BUCKETS = True
-    a, b, c, d = runs
+    a, b, b2, c = runs
     out = {"metric": f"decode ms/step under batch churn ({args.config}, B in [{lo_b}, {B}], ctx ~{ctx_mean})",
            "unit": "ms", "higher_is_better": False, "n_gpus": 1, "data": "synthetic",
            "config": {"workload": f"{args.config} decode under churn: {steps} decode steps, a prune + 0-2 request Prefill + "
                                   f"concatenate every 4-8 steps, seeded schedule, greedy", "pool_pages": cache.num_pages,
-                      "page_bytes": cache.num_kv_heads * 32 * cache.head_dim * 2, "default_page_classes": C0},
+                      "page_bytes": cache.num_kv_heads * 32 * cache.head_dim * 2},
            "runs": runs,
            "aged_over_pristine_p50": round(b["p50_ms"] / a["p50_ms"], 4),
-           "one_class_over_classes_p50": round(c["p50_ms"] / b["p50_ms"], 4),
+           "finely_aged_over_pristine_p50": round(b2["p50_ms"] / a["p50_ms"], 4),
            "p99_over_p50": {r["run"]: round(r["p99_ms"] / r["p50_ms"], 3) for r in runs}}
     print(json.dumps(out), flush=True)
 

@@ -50,10 +50,10 @@ def test_from_pb_left_truncation_and_bos():
 
 
 def test_pages_are_taken_lowest_first_and_page_major():
-    """kv_cache.py, one residue class (the round-5 policy): the pool hands out its lowest free ids, and a batch lays them
+    """kv_cache.py: the pool hands out its lowest free ids, and a batch lays them
     PAGE-major over its sequences (what the decode blocks read at one instant is then a dense run of the pool); a finished
     sequence's pages are the next ones out."""
-    cache = PagedKVCache(1, 1, 64, 32, torch.float16, CPU, classes=1)
+    cache = PagedKVCache(1, 1, 64, 32, torch.float16, CPU)
     a = _batch([[5] * 70, [6] * 33, [7] * 3], 40, batch_id=1)   # 3 + 2 + 1 pages
     a.allocate_pages(cache)
     assert a.pages == [[0, 3, 5], [1, 4], [2]]
@@ -70,92 +70,46 @@ def test_pages_are_taken_lowest_first_and_page_major():
     assert cache.free_pages == 32 and cache.alloc(4) == [0, 1, 2, 3]
 
 
-def test_residue_classes_pristine_pool_is_the_dense_page_major_run():
-    """kv_cache.py, C residue classes: page p of the sequence in lane l comes from class (l + p) mod C, lowest id first.  On
-    a pristine pool a batch of C sequences gets row p = the ids [p C, p C + C) — the dense page-major run of round 5."""
-    C = 8
-    cache = PagedKVCache(1, 1, 64, 64, torch.float16, CPU, classes=C)
-    a = _batch([[5] * 70] * C, 40)                              # 3 pages each
-    a.allocate_pages(cache)
-    assert a.lanes == list(range(C))
-    for p in range(3):
-        row = [a.pages[i][p] for i in range(C)]
-        assert sorted(row) == list(range(p * C, p * C + C)), row
-        assert [pg % C for pg in row] == [(i + p) % C for i in range(C)]
-    a.input_lengths = [97] * C
-    a.grow_pages()
-    assert sorted(a.pages[i][3] for i in range(C)) == list(range(3 * C, 4 * C))
-    a.release()
-    assert cache.free_pages == 64 and cache.null_page == 64 and cache.pool.shape[2] == 65 and cache._lane_use == [0] * C
-
-
-def test_residue_classes_survive_churn():
-    """after the pool has churned (random alloc / free, then requests joining and leaving a running batch
-    through prefill + concatenate + prune, as the router drives it, flash_causal_lm.py:196-353) the pages that the decode
-    blocks read at the same instant — page p of every live sequence — still cover the residue classes evenly: no class holds
-    more than ceil(B / C) pages of any full row, and (with half the pool free) every page came from the class it asked for."""
+def test_churned_pool_keeps_columns_and_the_null_page_is_never_handed_out():
+    """Round 6: requests join and leave a running batch (prefill + concatenate + prune, the way the router drives the shard,
+    flash_causal_lm.py:196-353).  Lowest-id-first dealing means the request that replaces a finished one inherits its pages
+    (its column of the page-major layout); the null page (inactive rows of a bucketed decode graph) is outside the free list;
+    nothing leaks."""
     import random
 
     rng = random.Random(7)
-    C, B, npages = 16, 32, 4096
-    cache = PagedKVCache(1, 1, 64, npages, torch.float16, CPU, classes=C)
-    held = []
-    for _ in range(400):                                         # age the pool
-        if held and rng.random() < 0.5:
-            cache.free(held.pop(rng.randrange(len(held))))
-        else:
-            held.append(cache.alloc(rng.randrange(1, 40)))
-    for h in held[::2]:
-        cache.free(h)
-    held = held[1::2]
-    assert cache.free_pages > npages // 2
-    misses = [0, 0]
-    real_alloc = cache.alloc_classes
-
-    def counting(wants):
-        got = real_alloc(wants)
-        misses[0] += sum(1 for w, g in zip(wants, got) if g % C != w % C)
-        misses[1] += len(got)
-        return got
-
-    cache.alloc_classes = counting
-    run = _batch([[5] * rng.randrange(600, 700) for _ in range(B)], 400, batch_id=1)
+    B, npages = 8, 512
+    cache = PagedKVCache(1, 1, 64, npages, torch.float16, CPU)
+    assert cache.null_page == npages and cache.pool.shape[2] == npages + 1
+    run = _batch([[5] * 70 for _ in range(B)], 400, batch_id=1)
     run.allocate_pages(cache)
-    run.cu_seqlens_q = torch.arange(len(run) + 1, dtype=torch.int32)
+    assert [run.pages[i][p] for p in range(3) for i in range(B)] == list(range(3 * B))   # dense rows on the pristine pool
+    run.cu_seqlens_q = torch.arange(B + 1, dtype=torch.int32)
     next_id = B
-    for step in range(300):
+    for step in range(120):
         run.input_lengths = [n + 1 for n in run.input_lengths]
         run.position_ids = torch.tensor(run.input_lengths)
         run.input_ids = torch.zeros(len(run), dtype=torch.int64)
         run.grow_pages()
         if step % 6 == 5:
-            done = rng.sample([r.id for r in run.requests], rng.randrange(1, 3))
-            run = FlashCausalLMBatch.prune(run, done)
-            k = B - len(run) if rng.random() < 0.7 else max(0, B - len(run) - 1)
-            if k:
-                new = _batch([[6] * rng.randrange(500, 900) for _ in range(k)], 400, first_id=next_id, batch_id=2 + step)
-                next_id += k
-                new.allocate_pages(cache)
-                new.cu_seqlens_q = torch.arange(k + 1, dtype=torch.int32)
-                new.position_ids = torch.tensor(new.input_lengths)
-                new.input_ids = torch.zeros(k, dtype=torch.int64)
-                run = FlashCausalLMBatch.concatenate([run, new])
-        # rows every live sequence has: residues must stay spread
-        depth = min(len(p) for p in run.pages)
-        for p in range(0, depth, 5):
-            hist = [0] * C
-            for pages in run.pages:
-                hist[pages[p] % C] += 1
-            assert max(hist) <= (len(run) + C - 1) // C, (step, p, hist)   # as even as B sequences over C classes can be
-    assert misses[0] == 0 and misses[1] > 1000, misses
+            victim = rng.choice(run.requests).id
+            freed = sorted(run.pages[[r.id for r in run.requests].index(victim)])
+            run = FlashCausalLMBatch.prune(run, [victim])
+            new = _batch([[6] * 70], 400, first_id=next_id, batch_id=2 + step)
+            next_id += 1
+            new.allocate_pages(cache)
+            assert new.pages[0] == freed[:3], "the newcomer takes the lowest free ids: the column that was just vacated"
+            new.cu_seqlens_q = torch.arange(2, dtype=torch.int32)
+            new.position_ids = torch.tensor(new.input_lengths)
+            new.input_ids = torch.zeros(1, dtype=torch.int64)
+            run = FlashCausalLMBatch.concatenate([run, new])
+        assert all(pg < npages for p in run.pages for pg in p), "the null page was handed out"
     run.release()
-    for h in held:
-        cache.free(h)
-    assert cache.free_pages == npages and cache._lane_use == [0] * C
+    assert cache.free_pages == npages
 
 
 def test_page_ownership_concat_prune_release():
-    cache = PagedKVCache(2, 2, 64, 16, torch.float16, CPU, classes=1)
+    cache = PagedKVCache(2, 2, 64, 16, torch.float16, CPU)
     a = _batch([[5] * 70, [6] * 33], 40, batch_id=1)         # prompt + first token: 71 and 34 slots -> 3 + 2 pages
     a.allocate_pages(cache)                                  # (max_output_length 40 reserves nothing up front)
     assert [len(p) for p in a.pages] == [3, 2] and cache.free_pages == 11

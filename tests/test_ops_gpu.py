@@ -290,8 +290,10 @@ def test_attention_decode_every_fill_of_the_last_page(nat, gpu_device, H, Hkv):
     dummy[:, H * D:] = kv
     slots = torch.cat([bt[b, torch.arange(l) // 32].long() * 32 + torch.arange(l) % 32 for b, l in enumerate(lens)]).int()
     # every slot starts as large finite garbage, the scatter then writes the real tokens
-    kpool = torch.full((total_pages, Hkv, 32 * D), 3.0e4, dtype=dtype, device=gpu_device)
-    vpool = torch.full((total_pages, Hkv, 32 * D), -3.0e4, dtype=dtype, device=gpu_device)
+    # (the extreme finite f16 values: what a reused page's stale tail can hold at worst — the pool's invariant, utils/kv_cache.py,
+    # is that every value ever written to it is finite)
+    kpool = torch.full((total_pages, Hkv, 32 * D), 65504.0, dtype=dtype, device=gpu_device)
+    vpool = torch.full((total_pages, Hkv, 32 * D), -65504.0, dtype=dtype, device=gpu_device)
     nat.rope_kv_write(dummy.to(gpu_device), None, None, None, slots.to(gpu_device), kpool, vpool, H, Hkv, D, D)
     for b, l in enumerate(lens):
         nv, pg = l - 64, int(bt[b, 2])

@@ -660,10 +660,13 @@ extern "C" int tgis_attn_num_splits(int64_t B, int Hkv, int H, int64_t max_q_len
         // (tools/attn_nw.py, us: B=16 GQA 8:1 D=64 ctx 512: 6.8 unsplit vs 8.5 at 4 splits of 4 waves;
         //  B=1 MHA D=128 ctx 2048: 14.1 at 8 splits vs 17.7 at 16; B=4 GQA 4:1 ctx 4096: 19.0 at 8 vs 24.0 at 16)
         ns = std::min<int64_t>(cdiv64(256, base), pages / 16);
-        // from 128 groups on the merge costs more than the second half of the CUs gives (round 5, a 7B rank at TP = 8: B 32 x 4
-        // heads, ctx 1024: 15.8 us unsplit, 16.5 at 2 splits; 64 groups, ctx 2048: 24.0 / 19.2 / 17.7 at 1 / 2 / 4 —
-        // profiles/r05_attn_tp8.log)
-        if (base >= 128) ns = 1;
+        // From 128 groups on the merge costs more than the second half of the CUs gives while the context is short (a 7B rank at
+        // TP = 8, B 32 x 4 heads, ctx 1024: 16.0 us unsplit, 16.5 at 2 splits; 64 groups, ctx 2048: 24.0 / 19.2 / 17.7 at
+        // 1 / 2 / 4 — profiles/r05_attn_tp8.log).  Round 6 swept it over the context (profiles/r06_attn_base128.log): exactly
+        // 128 groups take 2 splits from ctx 2048 on (26.9 vs 29.1 us, 46.0 vs 51.7 at 4096, 166.6 vs 194.8 at 16384: the page
+        // walk grows, the merge does not); 129 - 255 groups never do (2 splits would be a second round of blocks: 192 groups
+        // 41.2 vs 34.9 at 2048, 272.8 vs 243.5 at 16384).
+        if (base >= 128) ns = (base * 2 <= 256 && pages >= 64) ? 2 : 1;
     } else if (ch > 1) {
         // multi-chunk blocks hold three sets of accumulators: one block per CU, one wave per SIMD, so the block's time is
         // its waves' page count (~1 us per page: issue-bound) plus ~12 us.  Their splits are merged by the combine launch,

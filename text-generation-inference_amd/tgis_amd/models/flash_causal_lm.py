@@ -68,7 +68,6 @@ class FlashCausalLMBatch(Batch):
     # paged-KV ownership: page ids per request, filled by the prefill generate_token
     kv_cache: Optional[PagedKVCache] = None
     pages: Optional[List[List[int]]] = None
-    lanes: Optional[List[int]] = None  # kv_cache.py: which residue class of the pool page p of a sequence comes from
     block_tables: Optional[torch.Tensor] = None
 
     def get_id(self) -> int:
@@ -84,16 +83,15 @@ class FlashCausalLMBatch(Batch):
         batch-weight model (router/src/batch_types.rs:46-118) counts tokens present, not max_output_length."""
         assert self.pages is None
         need = [PagedKVCache.pages_for(n + 1) for n in self.input_lengths]
-        lanes = kv_cache.new_lanes(len(need))
-        # page-major: page p of every sequence, then page p + 1; page p of the sequence in lane l comes from residue class
-        # l + p of the pool (kv_cache.py: the pages the decode blocks read at the same time are a dense run of a pristine
-        # pool and cover the classes evenly in a churned one).  One all-or-nothing request: OutOfPages before anything is taken.
-        order = [(p, i) for p in range(max(need, default=0)) for i in range(len(need)) if p < need[i]]
-        flat = kv_cache.alloc_classes([lanes[i] + p for p, i in order])
-        self.kv_cache, self.lanes = kv_cache, lanes
-        self.pages = [[] for _ in need]
-        for (p, i), pg in zip(order, flat):
-            self.pages[i].append(pg)
+        flat = kv_cache.alloc(sum(need))  # raises OutOfPages before anything is taken
+        self.kv_cache = kv_cache
+        # page-major: page p of every sequence, then page p + 1 (kv_cache.py: the pages the decode blocks read at the same
+        # time are then neighbours in the pool)
+        self.pages, it = [[] for _ in need], iter(flat)
+        for p in range(max(need, default=0)):
+            for i in range(len(need)):
+                if p < need[i]:
+                    self.pages[i].append(next(it))
         self._rebuild_block_tables()
 
     def grow_pages(self):
@@ -101,8 +99,7 @@ class FlashCausalLMBatch(Batch):
         short = [i for i, (p, n) in enumerate(zip(self.pages, self.input_lengths)) if len(p) * PAGE < n]
         if not short:
             return
-        # all or nothing: OutOfPages leaves the batch as it was
-        flat = self.kv_cache.alloc_classes([self.lanes[i] + len(self.pages[i]) for i in short])
+        flat = self.kv_cache.alloc(len(short))  # all or nothing: OutOfPages leaves the batch as it was
         for i, pg in zip(short, flat):
             self.pages[i].append(pg)
         width = self.block_tables.shape[1]
@@ -128,8 +125,7 @@ class FlashCausalLMBatch(Batch):
         if self.pages is not None and self.kv_cache is not None:
             for p in self.pages:
                 self.kv_cache.free(p)
-            self.kv_cache.drop_lanes(self.lanes or [])
-        self.pages = self.lanes = None
+        self.pages = None
         self.block_tables = None
 
     def __del__(self):
@@ -215,7 +211,7 @@ class FlashCausalLMBatch(Batch):
     def concatenate(cls, batches: List["FlashCausalLMBatch"]) -> "FlashCausalLMBatch":
         first = batches[0]
         device = first.cu_seqlens_q.device
-        requests, input_lengths, total_lengths, pages, lanes = [], [], [], [], []
+        requests, input_lengths, total_lengths, pages = [], [], [], []
         chooser_params, ntc_current_tokens, ntc_samplings, ntc_return_logprobs = [], [], [], []
         input_ids, position_ids = [], []
         cu_seqlens = [torch.tensor([0], dtype=torch.int32, device=device)]
@@ -239,7 +235,6 @@ class FlashCausalLMBatch(Batch):
             # no KV bytes move (reference: torch.cat of the pasts); ownership of the pages changes hands below, once
             # the merged batch exists — an exception before that leaves every page with its source batch
             pages.extend(batch.pages)
-            lanes.extend(batch.lanes)
             end = start + len(batch)
             all_input_ids_tensor[start:end, :batch.all_input_ids_tensor.shape[1]] = batch.all_input_ids_tensor
             start = end
@@ -260,14 +255,14 @@ class FlashCausalLMBatch(Batch):
             total_lengths=total_lengths, all_input_ids_tensor=all_input_ids_tensor,
             next_token_chooser=next_token_chooser, pad_token_id=first.pad_token_id,
             kv_cache=first.kv_cache, pages=None)
-        merged.pages, merged.lanes = pages, lanes
+        merged.pages = pages
         try:
             merged._rebuild_block_tables()
         except BaseException:
-            merged.pages = merged.lanes = None  # the sources still own them
+            merged.pages = None  # the sources still own them
             raise
         for batch in batches:
-            batch.pages = batch.lanes = None
+            batch.pages = None
             batch.block_tables = None
         return merged
 
@@ -285,10 +280,8 @@ class FlashCausalLMBatch(Batch):
         for i, p in enumerate(batch.pages):
             if i not in keep:
                 batch.kv_cache.free(p)
-                batch.kv_cache.drop_lanes(batch.lanes[i:i + 1])
         pick = (lambda l: [l[i] for i in keep_indices])
         batch.pages = pick(batch.pages)
-        batch.lanes = pick(batch.lanes)
         batch.input_lengths = pick(batch.input_lengths)
         batch.total_lengths = pick(batch.total_lengths)
         batch.requests = pick(batch.requests)

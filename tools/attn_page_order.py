@@ -116,23 +116,48 @@ def more_rounds(B=64, H=32, Hkv=32, D=128, ctx=1023, sets=4):
             print(f"  {name:42s} {t:7.2f} us   {B * ctx * 2 * Hkv * D * 2 / t / 1e6:6.2f} TB/s")
 
 
+class ClassPool:
+    """Round 6, VERDICT r05 item 2a — measured, not kept in the product: a free list with one heap per residue class of the
+    page id (C classes); page p of the sequence in lane l is taken from class (l + p) mod C, lowest id first, an empty class
+    is replaced by the fullest one.  C = 1 is the product's allocator (utils/kv_cache.py: lowest free id first)."""
+
+    def __init__(self, num_pages, C):
+        import heapq
+
+        self.hq, self.C, self.num_pages = heapq, C, num_pages
+        self.heaps = [list(range(c, num_pages, C)) for c in range(C)]
+        self.free_pages = num_pages
+
+    def alloc_classes(self, wants):
+        out = []
+        for w in wants:
+            h = self.heaps[w % self.C]
+            if not h:
+                h = max(self.heaps, key=len)
+            out.append(self.hq.heappop(h))
+        self.free_pages -= len(out)
+        return out
+
+    def free(self, pages):
+        for p in pages:
+            self.hq.heappush(self.heaps[p % self.C], p)
+        self.free_pages += len(pages)
+
+
 def aged_tables(C, B, P, cap, seed=0):
-    """Block tables [B, P] the product's allocator (utils/kv_cache.py, C residue classes) hands a batch on a pool of `cap`
-    pages that has churned: random allocations and frees first, half of what is held then freed."""
+    """Block tables [B, P] a C-class free list hands a batch (dealt page-major, sequence b in lane b) on a pool of `cap` pages
+    that has churned: random allocations and frees first, then enough of what is held freed again."""
     import random
 
-    from tgis_amd.utils.kv_cache import PagedKVCache
-
     rng = random.Random(seed)
-    cache = PagedKVCache(1, 1, 8, cap, torch.float16, torch.device("cpu"), classes=C)
+    cache = ClassPool(cap, C)
     held = []
     while cache.free_pages > cap // 4:
-        held.append(cache.alloc(rng.randrange(1, 48)))
+        held.append(cache.alloc_classes(range(rng.randrange(1, 48))))
     rng.shuffle(held)
     while cache.free_pages < B * P + cap // 8:
         cache.free(held.pop())
-    lanes = cache.new_lanes(B)
-    flat = cache.alloc_classes([lanes[b] + p for p in range(P) for b in range(B)])
+    flat = cache.alloc_classes([b + p for p in range(P) for b in range(B)])
     return torch.tensor(flat, dtype=torch.int32).view(P, B).t().contiguous()
 
 
