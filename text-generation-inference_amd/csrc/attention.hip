@@ -103,94 +103,22 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
 
     // Q^T fragments (B operand): lane supplies Q[col][ks*32 + c*8 .. +8]
     V8 qf[CH][KS];
-    if (!a.fused_rope) {
 #pragma unroll
-        for (int ch = 0; ch < CH; ++ch) {
-            const int head = hk * a.G + (hc0 + ch) * 16 + g;
-            const T* qp = reinterpret_cast<const T*>(a.q) + (int64_t)(q0 + t0 + tq) * a.ld_q + (int64_t)head * D + c * 8;
+    for (int ch = 0; ch < CH; ++ch) {
+        const int head = hk * a.G + (hc0 + ch) * 16 + g;
+        const T* qp = reinterpret_cast<const T*>(a.q) + (int64_t)(q0 + t0 + tq) * a.ld_q + (int64_t)head * D + c * 8;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (col_valid[ch]) {
-                    qf[ch][ks] = ld16<V8>(qp + ks * 32);
-                } else {
+        for (int ks = 0; ks < KS; ++ks) {
+            if (col_valid[ch]) {
+                qf[ch][ks] = ld16<V8>(qp + ks * 32);
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) qf[ch][ks][e] = (T)0.f;
-                }
+                for (int e = 0; e < 8; ++e) qf[ch][ks][e] = (T)0.f;
             }
-        }
-    } else {
-        // Decode (q_len == 1) straight from the qkv GEMM's output: what rope_kv_kernel does in a launch of its own —
-        // finish the split-K sum, rotate q and k (fp32 on the model-dtype tables), scatter the new token's k and v into
-        // its page — happens here, with the same arithmetic.  The block that owns the last page writes the token
-        // (blocks of other head chunks of the same kv head write the same values) and only then walks its pages.
-        // Measured (tools/attn_fused_bench.py): NOT faster than the two launches — cfg3 104 us vs 93 (attention alone
-        // 81.5): the q prologue is a dependent chain (position -> tables and slabs -> rotate) in front of every
-        // block's first K/V load, +6 us; the 128 two-byte v stores per (sequence, head) into lines the same launch
-        // then reads cost +13 us, the k stores +4.  The model keeps the stand-alone kernel (TGIS_FUSED_ROPE_ATTN).
-        const int64_t t = q0;
-        const PartialIn<T> pin{a.qkv_slabs, a.qkv_S, a.qkv_slab_ld, reinterpret_cast<const T*>(a.qkv_bias)};
-        const T* row = reinterpret_cast<const T*>(a.q) + (pin.slabs ? 0 : t * a.ld_q);
-        const bool rotary = a.cosb != nullptr;
-        const int half = a.rot >> 1;
-        const int64_t tab = rotary ? (int64_t)a.positions[t] * half : 0;
-        const T* cr = reinterpret_cast<const T*>(a.cosb) + tab;
-        const T* sr = reinterpret_cast<const T*>(a.sinb) + tab;
-        // 8 consecutive dims d0.. of head `head` (index in the [q heads | k heads | v heads] layout), rotated
-        auto roped8 = [&](const int head, const int d0, const bool rot_this) -> V8 {
-            const int colx = head * D + d0;
-            const V8 own = load_chunk<T>(row + colx, t, colx, pin);
-            if (!rot_this || d0 >= a.rot) return own;
-            const bool lower = d0 < half;
-            const int dp = lower ? d0 + half : d0 - half;  // the partner chunk
-            const V8 oth = load_chunk<T>(row + head * D + dp, t, head * D + dp, pin);
-            const int ci = lower ? d0 : dp;
-            const V8 cv = ld16<V8>(cr + ci), sv = ld16<V8>(sr + ci);
-            V8 r;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float cf = to_f32(cv[e]), sf = to_f32(sv[e]);
-                if (lower) {
-                    const float x1 = to_f32(own[e]), x2 = to_f32(oth[e]);
-                    r[e] = from_f32<T>(x1 * cf - x2 * sf);
-                } else {
-                    const float x1 = to_f32(oth[e]), x2 = to_f32(own[e]);
-                    r[e] = from_f32<T>(x1 * sf + x2 * cf);
-                }
-            }
-            return r;
-        };
-#pragma unroll
-        for (int ch = 0; ch < CH; ++ch) {
-            const int head = hk * a.G + (hc0 + ch) * 16 + g;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (col_valid[ch]) {
-                    qf[ch][ks] = roped8(head, ks * 32 + c * 8, rotary);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) qf[ch][ks][e] = (T)0.f;
-                }
-            }
-        }
-        const int last_page = (ctx - 1) >> 5;
-        if (last_page >= pbeg && last_page < pend) {  // block-uniform
-            constexpr int C8 = D / 8;
-            const int slot = a.slots[t];
-            const int page = slot >> 5, tok = slot & 31;
-            if (tid < C8) {
-                T* kb = const_cast<T*>(reinterpret_cast<const T*>(a.kpool)) + ((int64_t)page * a.Hkv + hk) * 32 * D;
-                st16(kb + k_off(tok, tid * 8, D), roped8(a.H + hk, tid * 8, rotary));
-            } else if (tid < 2 * C8) {
-                const int j = tid - C8;
-                const V8 v = roped8(a.H + a.Hkv + hk, j * 8, false);
-                T* vb = const_cast<T*>(reinterpret_cast<const T*>(a.vpool)) + ((int64_t)page * a.Hkv + hk) * 32 * D + v_off(tok, 0, D);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vb[(int64_t)(j * 8 + e) * 8] = v[e];
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left this CU before any wave reads the page
-            __syncthreads();
         }
     }
+    // (Rotary embedding + cache write of the new token in this prologue was built in round 2, bit-exact, and measured slower
+    // than the launch in front: cfg3 104 vs 93 us — experiments/README.md.)
 
     f32x4 o[CH][NB];
     float m[CH], lsum[CH];
@@ -808,26 +736,12 @@ struct CounterLease {  // gives the slot back when the launch is in its stream (
 };
 }  // namespace
 
-namespace {
-struct FusedRope {  // the rotary + cache-write prologue of tgis_attn_decode_rope
-    const float* slabs;
-    int S;
-    int64_t slab_ld;
-    const void* bias;
-    const void* cos;
-    const void* sin;
-    const int32_t* positions;
-    const int32_t* slots;
-    int rot;
-};
-}  // namespace
-
 static int attn_paged_impl(const void* q, int64_t ld_q, const void* k_pool, const void* v_pool,
                            const int32_t* block_tables, int64_t max_pages, const int32_t* ctx_lens,
                            const int32_t* cu_seqlens_q, void* out, int64_t ld_out, int64_t B, int H, int Hkv, int D,
                            int64_t max_q_len, int64_t max_ctx, float scale, int dtype, int num_splits,
-                           void* workspace, int64_t workspace_bytes, void* stream, const FusedRope* fr) {
-    TGIS_CHECK_ARG((q || (fr && fr->slabs)) && k_pool && v_pool && block_tables && ctx_lens && cu_seqlens_q && out,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+    TGIS_CHECK_ARG(q && k_pool && v_pool && block_tables && ctx_lens && cu_seqlens_q && out,
                    "tgis_attn_paged: null tensor");
     TGIS_CHECK_ARG(H > 0 && Hkv > 0 && H % Hkv == 0, "tgis_attn_paged: H (%d) must be a multiple of Hkv (%d)", H, Hkv);
     TGIS_CHECK_ARG(D == 64 || D == 128, "tgis_attn_paged: head_dim %d not supported (64, 128)", D);
@@ -870,16 +784,6 @@ static int attn_paged_impl(const void* q, int64_t ld_q, const void* k_pool, cons
     a.ws_o = nullptr;
     a.ws_ml = nullptr;
     a.counters = nullptr;
-    a.fused_rope = fr ? 1 : 0;
-    a.qkv_slabs = fr ? fr->slabs : nullptr;
-    a.qkv_S = fr ? fr->S : 0;
-    a.qkv_slab_ld = fr ? fr->slab_ld : 0;
-    a.qkv_bias = fr ? fr->bias : nullptr;
-    a.cosb = fr ? fr->cos : nullptr;
-    a.sinb = fr ? fr->sin : nullptr;
-    a.positions = fr ? fr->positions : nullptr;
-    a.slots = fr ? fr->slots : nullptr;
-    a.rot = fr ? fr->rot : 0;
     int64_t total_q = 0;
     CounterLease lease;
     if (num_splits > 1) {
@@ -938,6 +842,6 @@ extern "C" int tgis_attn_paged(const void* q, int64_t ld_q, const void* k_pool, 
                                int64_t max_q_len, int64_t max_ctx, float scale, int dtype, int num_splits,
                                void* workspace, int64_t workspace_bytes, void* stream) {
     return attn_paged_impl(q, ld_q, k_pool, v_pool, block_tables, max_pages, ctx_lens, cu_seqlens_q, out, ld_out, B, H, Hkv, D,
-                           max_q_len, max_ctx, scale, dtype, num_splits, workspace, workspace_bytes, stream, nullptr);
+                           max_q_len, max_ctx, scale, dtype, num_splits, workspace, workspace_bytes, stream);
 }
 

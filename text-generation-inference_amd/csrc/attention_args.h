@@ -21,19 +21,6 @@ struct AttnArgs {
     float* ws_o;   // [total_q][H][NS][D]        (fused combine: [group][chunk][16 columns][NS][D])
     float* ws_ml;  // [total_q][H][NS][2]        (fused combine: [group][chunk][16 columns][NS][4], {m, l, -, -})
     unsigned* counters;  // fused combine: per-group arrival counters (zero between launches), or nullptr
-    // Decode with the rotary embedding and the cache write of the new token in the prologue (tgis_attn_decode_rope):
-    // q points at the un-rotated qkv activation [T, ld_q] (or is unused when qkv_slabs holds the qkv GEMM's split-K
-    // partial sums); kpool / vpool are written at slots[t] before the block that owns the last page reads it.
-    int fused_rope;            // 0: q is the rotated q of a finished qkv activation (the stand-alone rope kernel ran)
-    const float* qkv_slabs;    // [S][32][qkv_slab_ld] or nullptr
-    int qkv_S;
-    int64_t qkv_slab_ld;
-    const void* qkv_bias;      // T [(H + 2 Hkv) D] or nullptr (slab input only)
-    const void* cosb;          // T [max_pos, rot / 2] or nullptr (no rotation: cache write only)
-    const void* sinb;
-    const int32_t* positions;  // [T]
-    const int32_t* slots;      // [T]
-    int rot;
 };
 
 constexpr float NEG_BIG = -1.0e30f;

@@ -1,11 +1,5 @@
-// The dense (f16 / bf16 weights) skinny GEMM as a device function, shared by the stand-alone kernel (gemm_dense.hip)
-// and the persistent decode-tail kernel (decode_tail.hip), plus the launch planning both use.
-//
-// TAIL = false: one workgroup = one unit, block-wide s_barrier, plain loads and stores.
-// TAIL = true : the unit runs inside a persistent workgroup next to waves that may take no part (its waves meet at an
-//   LDS counter instead of s_barrier); the activation is read with sc1 (L1-bypassing) loads and the results leave as
-//   16-byte sc1 (write-through) stores assembled through LDS — the same inter-workgroup protocol as gptq_gemm_body.h,
-//   whose LDS layout constants (x region, control line) the dense unit shares.
+// The dense (f16 / bf16 weights) skinny GEMM as a device function (one workgroup = one unit) plus its launch planning; the
+// kernel that runs it is in gemm_dense.hip.  (The persistent decode-tail form of rounds 2 - 5 is gone: experiments/README.md.)
 #pragma once
 #include "gptq_gemm_body.h"
 #include "kv_layout.h"
@@ -13,11 +7,6 @@
 namespace dense {
 
 using gptq::lds_int;
-using gptq::TAIL_CTRL;
-using gptq::TAIL_SPIN_LIMIT;
-using gptq::UNIT_FULL;
-using gptq::UNIT_PREFETCH;
-using gptq::UNIT_RUN;
 
 struct DenseArgs {
     const void* x;
@@ -34,7 +23,6 @@ struct DenseArgs {
     float* slabs;  // [Mslabs][S][32][NT*32] f32 partial sums (S > 1 or partial mode)
     int partial;   // 1: always leave fp32 slabs (deferred reduce), never write `out`
     int gelu;      // model-dtype output only: 0 none, 1 GELU (erf), 2 GELU (tanh) applied to the rounded sum + bias
-    unsigned* err; // decode tail: word that receives a code when a bounded spin gives up (nullptr otherwise)
     // ACT == 3 (rope image, tgis_dense_prepare flags bit 1): the epilogue rotates q / k heads and writes k / v into their
     // cache pages; `out` is the q tensor (see tgis_dense_gemm_rope)
     const int32_t* positions;  // [M]
@@ -50,12 +38,6 @@ constexpr int DKC = 256;      // k per LDS chunk (4 k64-steps)
 constexpr int DRS = DKC + 8;  // LDS row stride in elements (+16 B -> conflict-free ds_read_b128)
 constexpr int DRING = 2;      // k64-steps of weights in flight per wave (2 x 4 KiB)
 static_assert(DKC == gptq::KC && DRS == gptq::RS, "the dense unit shares the LDS layout of the int4 unit");
-
-// The weights a wave has in flight (decode tail: filled before the grid barrier in front of the phase).
-template <typename T>
-struct DenseRing {
-    typename VecT<T>::x8 wq[DRING][4];
-};
 
 // sum + bias -> model dtype; with `gelu` the activation of the ROUNDED value (what tgis_gelu would read back), rounded again
 template <typename T>
@@ -77,14 +59,12 @@ __device__ __forceinline__ T finish_out(float v, int gelu) {
 //   out[m][j] = T(T(silu(T gate)) * T up), [rows, N/2] — once per element, where ACT = 1 recomputes the SiLU in every
 //   column block of the consumer.  Needs S == 1 (the planner guarantees it).
 // MR = 32-row blocks of x per pass (2 for M > 32: every weight fragment then feeds two MFMAs; needs WK = 2).
-template <typename T, int TN, int WK, int ACT, int MR, bool TAIL, int MODE>
+template <typename T, int TN, int WK, int ACT, int MR>
 __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int ntg, const int split, const int mslab,
-                                                unsigned char* smem, const int ub_base, DenseRing<T>& ring) {
+                                                unsigned char* smem) {
     static_assert(MR == 1 || WK == 2, "64-row passes need the LDS of two k-parts");
-    static_assert(!TAIL || MR == 1, "the decode tail runs 32-row units");
-    static_assert(ACT != 3 || !TAIL, "the rope epilogue belongs to the stand-alone kernel");
+    static_assert(WK > 1, "the finish below exchanges k-parts");
     using V8 = typename VecT<T>::x8;
-    constexpr int NWAVES = TN * WK;
     constexpr int XR = 32 * MR;
     constexpr int GT = 64 * TN;
     constexpr int NJ = (XR * 32 + GT - 1) / GT;
@@ -106,19 +86,13 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
 
     const char* wtile = reinterpret_cast<const char*>(a.prep) + (int64_t)nt * a.KS * 4096;
     const uint32_t woff = lane * 16;
-    V8 (&wq)[DRING][4] = ring.wq;
+    V8 wq[DRING][4];  // the weights a wave has in flight
     auto w_load = [&](int step, V8* dst) {
         const char* p = wtile + (int64_t)min(ks0 + step, ks_clamp) * 4096;
         PIN_SGPR(p);  // wave-uniform base in SGPRs: (sgpr base + lane offset) addressing
 #pragma unroll
         for (int i = 0; i < 4; ++i) dst[i] = __builtin_nontemporal_load((const GLOBAL_AS V8*)(p + i * 1024 + woff));
     };
-    if (MODE == UNIT_PREFETCH) {
-        // only the loads that do not depend on the activation; no LDS is touched (the previous unit may still run)
-#pragma unroll
-        for (int s = 0; s < DRING; ++s) w_load(s, wq[s]);
-        return;
-    }
 
     // ACT 3: cache slot and rotary position of the rows this wave will finish (distributed finish below)
     int32_t rpos[ACT == 3 ? MR : 1][ACT == 3 ? 16 / WK : 1], rslot[ACT == 3 ? MR : 1][ACT == 3 ? 16 / WK : 1];
@@ -143,8 +117,6 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
     uint32_t rowoff[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) rowoff[j] = (uint32_t)(min(srow + RSTEP * j, mrows - 1) * (int)a.ldx * 2);
-    // TAIL: x was written by other workgroups of this launch -> sc1 loads (a CU's L1 is never refreshed by other CUs)
-    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xbase), 0, 0x7FFFFFFF, 0x00020000);
     auto stage_load = [&](int chunk) {
         const int kk = k0 + chunk * DKC + scol;
         xok = kk < k1;
@@ -154,14 +126,8 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const uint32_t off = rowoff[j] + (uint32_t)kc * 2;
-            if (TAIL) {
-                xg[j] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 16));
-                if (ACT == 1)
-                    xu[j] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off + (uint32_t)a.K * 2, 0, 16));
-            } else {
-                xg[j] = *(const GLOBAL_AS V8*)(xb + off);
-                if (ACT == 1) xu[j] = *(const GLOBAL_AS V8*)(xb + (int64_t)a.K * 2 + off);
-            }
+            xg[j] = *(const GLOBAL_AS V8*)(xb + off);
+            if (ACT == 1) xu[j] = *(const GLOBAL_AS V8*)(xb + (int64_t)a.K * 2 + off);
         }
     };
     auto stage_store = [&](int buf) {
@@ -193,53 +159,24 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
         for (int i = 0; i < 2; ++i) accs[mr][i] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int xoff = (lane & 31) * DRS + (lane >> 5) * 32;
 
-    volatile lds_int* sync_cnt =
-        (volatile lds_int*)(smem + (TAIL ? (size_t)TAIL_CTRL : (size_t)WK * 2 * XR * DRS * sizeof(T))) + wk;
-    volatile lds_int* ubar = (volatile lds_int*)(smem + TAIL_CTRL) + 8;
-    int ub_target = ub_base;
-    // all NWAVES waves of the unit meet here; the LDS traffic a wave issued before is complete when it arrives
+    volatile lds_int* sync_cnt = (volatile lds_int*)(smem + (size_t)WK * 2 * XR * DRS * sizeof(T)) + wk;
+    // all waves of the unit meet here; the LDS traffic a wave issued before is complete when it arrives
     auto unit_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!TAIL) {
-            __builtin_amdgcn_s_barrier();
-        } else {
-            ub_target += NWAVES;
-            if (lane == 0) __hip_atomic_fetch_add((lds_int*)ubar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            for (unsigned spins = 0; __builtin_amdgcn_readfirstlane(*ubar) < ub_target; ++spins) {
-                __builtin_amdgcn_s_sleep(1);
-                if (spins > TAIL_SPIN_LIMIT) {  // never hang the device: flag the launch as failed and go on
-                    if (a.err && lane == 0) __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-            asm volatile("" ::: "memory");
-        }
+        __builtin_amdgcn_s_barrier();
     };
     if (wn == 0 && lane == 0) *sync_cnt = 0;
     stage_load(0);  // x first: a wave's loads return in order and this one is L2-resident
-    // stand-alone kernel: the barrier that publishes the zeroed counters sits between the x requests and the weight
-    // requests of EVERY wave, so that no wave's first x chunk queues behind another wave's HBM requests in the CU's
-    // memory pipeline (as in gptq_gemm_unit)
-    if (!TAIL) unit_barrier();
-    if (MODE == UNIT_FULL) {
+    // the barrier that publishes the zeroed counters sits between the x requests and the weight requests of EVERY wave, so
+    // that no wave's first x chunk queues behind another wave's HBM requests in the CU's memory pipeline (as in
+    // gptq_gemm_unit)
+    unit_barrier();
 #pragma unroll
-        for (int s = 0; s < DRING; ++s) w_load(s, wq[s]);
-    }
-    if (TAIL) unit_barrier();  // publishes the zeroed counters; does not wait for the loads above
+    for (int s = 0; s < DRING; ++s) w_load(s, wq[s]);
     auto group_sync = [&](int target) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add((lds_int*)sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!TAIL) {
-            while (__builtin_amdgcn_readfirstlane(*sync_cnt) < target) __builtin_amdgcn_s_sleep(1);
-        } else {
-            for (unsigned spins = 0; __builtin_amdgcn_readfirstlane(*sync_cnt) < target; ++spins) {
-                __builtin_amdgcn_s_sleep(1);
-                if (spins > TAIL_SPIN_LIMIT) {
-                    if (a.err && lane == 0) __hip_atomic_store(a.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
+        while (__builtin_amdgcn_readfirstlane(*sync_cnt) < target) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
     };
     stage_store(0);
@@ -276,7 +213,7 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
     };
     for (int chunk = 0; chunk + 1 < nchunks; ++chunk) chunk_body(chunk, std::false_type{});
     chunk_body(nchunks - 1, std::true_type{});
-    // stand-alone kernel, ACT 3: the cos / sin entries of the rows this wave will finish, asked for before the exchange
+    // ACT 3: the cos / sin entries of the rows this wave will finish, asked for before the exchange
     constexpr int NR = 16 / WK;
     T rcos[ACT == 3 ? MR : 1][ACT == 3 ? NR : 1], rsin[ACT == 3 ? MR : 1][ACT == 3 ? NR : 1];
     if (ACT == 3) {
@@ -297,11 +234,11 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
     f32x16 acc[MR];
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) acc[mr] = accs[mr][0] + accs[mr][1];
-    // ---- stand-alone kernel: distributed finish (as gptq_gemm_unit) -----------------------------------------------------
+    // ---- distributed finish (as gptq_gemm_unit) ---------------------------------------------------------------------------
     // Every wave leaves its partial sums in LDS; wave (wn, wk) sums the WK k-parts of accumulator registers
     // [wk NR, (wk + 1) NR) of tile wn in the fixed order 0..WK-1 (bit-identical to the reducer-wave form) and runs the
     // epilogue for those rows only.
-    if (!TAIL && WK > 1) {
+    {
         float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][MR][64 lanes][16]
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
@@ -417,165 +354,14 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
         }
         return;
     }
-    if (WK > 1) {
-        float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][MR][64 lanes][16]
-        if (wk > 0) {
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr) {
-                float* dst = red + ((((wk * TN + wn) * MR + mr) * 64 + lane) << 4);
-#pragma unroll
-                for (int r = 0; r < 16; r += 4)
-                    *reinterpret_cast<f32x4*>(dst + r) = f32x4{acc[mr][r], acc[mr][r + 1], acc[mr][r + 2], acc[mr][r + 3]};
-            }
-        }
-        unit_barrier();
-        if (wk > 0) {
-            if (TAIL) unit_barrier();  // the unit's LDS is free again only when its reducer waves are through
-            return;
-        }
-#pragma unroll
-        for (int k2 = 1; k2 < WK; ++k2)
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr) {
-                const float* src = red + ((((k2 * TN + wn) * MR + mr) * 64 + lane) << 4);
-#pragma unroll
-                for (int r = 0; r < 16; r += 4) {
-                    f32x4 t = *reinterpret_cast<const f32x4*>(src + r);
-                    acc[mr][r] += t[0];
-                    acc[mr][r + 1] += t[1];
-                    acc[mr][r + 2] += t[2];
-                    acc[mr][r + 3] += t[3];
-                }
-            }
-    }
-
-    // ---- epilogue: lane holds out[m = 32 mr + (r&3)+8(r>>2)+4(lane>>5)][n = nt*32 + (lane&31)] -------
-    if (TAIL) {
-        // Results leave as 16-byte sc1 stores: the 32 x 32 tile is laid out row-major in a private LDS scratch (beyond
-        // the k-part reduction area) and every lane then moves whole 16-byte row pieces.  Columns past N (the zero
-        // padding of the last tile) are only written to slabs, whose rows are NT*32 wide.
-        if (nt_raw < a.NT) {
-            unsigned char* scr = smem + NWAVES * 4096 + wn * 4096;
-            const int c = lane & 31;
-            if (ACT == 2) {
-                const int half = a.N >> 1;
-                const int j = nt * 16 + (c & 15);
-                const int nsrc = (c < 16) ? j : half + j;
-                const float bv = (a.bias && j < half) ? to_f32(reinterpret_cast<const T*>(a.bias)[nsrc]) : 0.f;
-                T* t = reinterpret_cast<T*>(scr);  // [32][16]
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float mine = to_f32(from_f32<T>(acc[0][r] + bv));
-                    const float other = __shfl_xor(mine, 16, 64);
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (c < 16) {
-                        float sl = mine / (1.f + __expf(-mine));
-                        t[m * 16 + c] = from_f32<T>(to_f32(from_f32<T>(sl)) * other);
-                    }
-                }
-                __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7FFFFFFF, 0x00020000);
-                const int row = lane >> 1, h8 = (lane & 1) * 8;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(t + row * 16 + h8);
-                if (row < mrows && nt * 16 + h8 + 8 <= half)
-                    __builtin_amdgcn_raw_buffer_store_b128(
-                        v, orsrc, (uint32_t)(((int64_t)(m0 + row) * a.ldo + nt * 16 + h8) * 2), 0, 16);
-            } else if (a.S == 1 && !a.partial) {
-                const int n = nt * 32 + c;
-                const float bv = (a.bias && n < a.N) ? to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
-                T* t = reinterpret_cast<T*>(scr);  // [32][32]
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    t[m * 32 + c] = from_f32<T>(acc[0][r] + bv);
-                }
-                __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7FFFFFFF, 0x00020000);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int p = i * 64 + lane, row = p >> 2, q8 = (p & 3) * 8;
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(t + row * 32 + q8);
-                    if (row < mrows && nt * 32 + q8 + 8 <= a.N)
-                        __builtin_amdgcn_raw_buffer_store_b128(
-                            v, orsrc, (uint32_t)(((int64_t)(m0 + row) * a.ldo + nt * 32 + q8) * 2), 0, 16);
-                }
-            } else {
-                float* t = reinterpret_cast<float*>(scr);  // [32][32]
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    t[m * 32 + c] = acc[0][r];
-                }
-                __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, 0x7FFFFFFF, 0x00020000);
-                const int64_t np = (int64_t)a.NT * 32;
-                const int64_t base = ((int64_t)(mslab * a.S + split) * 32) * np + nt * 32;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int p = i * 64 + lane, row = p >> 3, c4 = (p & 7) * 4;
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(t + row * 32 + c4);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, srsrc, (uint32_t)((base + row * np + c4) * 4), 0, 16);
-                }
-            }
-        }
-        unit_barrier();  // the unit's LDS may be reused from here on
-        return;
-    }
-    if (nt_raw >= a.NT) return;
-    const int n = nt * 32 + (lane & 31);
-    if (ACT == 2) {
-        // lanes c < 16 hold gate column j = 16 nt + c, lanes c + 16 the matching up column (rounding sequence of the
-        // reference's eager ops, flash_llama_modeling.py:332-335)
-        const int c = lane & 31;
-        const int half = a.N >> 1;
-        const int j = nt * 16 + (c & 15);
-        const int nsrc = (c < 16) ? j : half + j;
-        const float bv = (a.bias && j < half) ? to_f32(reinterpret_cast<const T*>(a.bias)[nsrc]) : 0.f;
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float mine = to_f32(from_f32<T>(acc[mr][r] + bv));
-                const float other = __shfl_xor(mine, 16, 64);
-                const int m = mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (c < 16 && j < half && m < mrows) {
-                    float sl = mine / (1.f + __expf(-mine));
-                    reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + j] = from_f32<T>(to_f32(from_f32<T>(sl)) * other);
-                }
-            }
-        return;
-    }
-    if (a.S == 1 && !a.partial) {
-        if (n >= a.N) return;
-        const float bv = a.bias ? to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= mrows) continue;
-                if (a.out_f32)
-                    reinterpret_cast<float*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = acc[mr][r] + bv;
-                else
-                    reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = finish_out<T>(acc[mr][r] + bv, a.gelu);
-            }
-    } else {
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr) {
-            float* sl = a.slabs + ((int64_t)((mslab * MR + mr) * a.S + split) * 32) * (a.NT * 32) + n;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                sl[(int64_t)m * (a.NT * 32)] = acc[mr][r];
-            }
-        }
-    }
 }
 
 struct DensePlan {
     int KR, S, WK, TN, MR;
 };
 
-// Plan of a unit inside the decode tail (M <= 32): at most `max_units` units (one per resident workgroup).  `direct`:
-// the consumer reads the output itself (gate_up feeding the SiLU staging of down), so no global k-split — the k-range
-// is spread over four in-block k-parts instead.
+// Plan with at most `max_units` units (one per CU).  `direct`: the output is finished in the epilogue (SiLU * up, rotary +
+// cache write), so no global k-split — the k-range is spread over four in-block k-parts instead.
 static inline DensePlan plan_dense_tail(int64_t K, int64_t N, bool direct, int64_t max_units) {
     const int64_t tiles = cdiv64(N, 32);
     const int64_t kchunks = cdiv64(K, DKC);

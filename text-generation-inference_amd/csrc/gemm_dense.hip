@@ -61,8 +61,7 @@ using dense::dense_slab_bytes;
 template <typename T, int TN, int WK, int ACT, int MR>
 __global__ __launch_bounds__(64 * TN * WK) void dense_gemm_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    dense::DenseRing<T> ring;
-    dense::dense_gemm_unit<T, TN, WK, ACT, MR, false, dense::UNIT_FULL>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem, 0, ring);
+    dense::dense_gemm_unit<T, TN, WK, ACT, MR>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 
@@ -216,7 +215,6 @@ static void dense_fill(DenseArgs& a, const void* x, int64_t ldx, const void* pre
     a.slabs = slabs;
     a.partial = partial;
     a.gelu = 0;
-    a.err = nullptr;
     a.positions = a.slots = nullptr;
     a.cosb = a.sinb = nullptr;
     a.kpool = a.vpool = nullptr;

@@ -98,12 +98,10 @@ __global__ void gptq_prepare_sz_kernel(const int32_t* __restrict__ qzeros, const
     sz[idx] = __builtin_bit_cast(uint32_t, v);
 }
 
-template <int TN, int WK, int ACT, bool GROUP64, bool PERM, int MR, bool NORMP = false>
+template <int TN, int WK, int ACT, bool GROUP64, bool PERM, int MR>
 __global__ __launch_bounds__(64 * TN * WK) void gptq_gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    gptq::WeightRing<4> ring;
-    gptq::gptq_gemm_unit<TN, WK, ACT, GROUP64, PERM, MR, false, 4, gptq::UNIT_FULL, NORMP>(a, blockIdx.x, blockIdx.y,
-                                                                                           blockIdx.z, smem, 0, ring);
+    gptq::gptq_gemm_unit<TN, WK, ACT, GROUP64, PERM, MR>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // Decode batches of up to 32 rows whose activation is in fragment order (gptq_wide_body.h).  8 waves; CT = 4 holds 2 waves
@@ -539,13 +537,10 @@ static int launch_tall(const void* x, int64_t ldx, const void* prepared, const v
     a.slabs = slabs;
     a.partial = partial;
     a.spg_shift = 30;
-    a.err = nullptr;
     a.positions = a.slots = nullptr;
     a.cosb = a.sinb = nullptr;
     a.kpool = a.vpool = nullptr;
     a.rH = a.rHkv = a.rD = 0;
-    a.norm = gsync::NormPhase{};
-    a.bar = nullptr;
     if (groups > 1)
         for (a.spg_shift = 0; (1 << a.spg_shift) < spg; ++a.spg_shift) {}
     const int BM = 32 * tp.BMR;
@@ -595,28 +590,16 @@ extern "C" int64_t tgis_gptq_gemm_workspace_bytes(int64_t M, int64_t K, int64_t 
     return need;
 }
 
-template <int TN, int WK, int ACT, bool G64, bool PERM, int MR, bool NORMP = false>
+template <int TN, int WK, int ACT, bool G64, bool PERM, int MR>
 static int launch_one(dim3 grid, size_t lds, hipStream_t st, const GemmArgs& a) {
     static bool attr_done = false;
     if (!attr_done) {
-        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_gemm_kernel<TN, WK, ACT, G64, PERM, MR, NORMP>,
+        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)gptq_gemm_kernel<TN, WK, ACT, G64, PERM, MR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * RS * 2 + 64));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gptq_gemm_kernel<TN, WK, ACT, G64, PERM, MR, NORMP>), grid, dim3(64 * TN * WK), lds, st, a);
+    hipLaunchKernelGGL((gptq_gemm_kernel<TN, WK, ACT, G64, PERM, MR>), grid, dim3(64 * TN * WK), lds, st, a);
     return TGIS_OK;
-}
-// the unit with the add + RMSNorm in front of it as its first phase (32-row gate_up / qkv + rope units)
-template <int ACT>
-static int launch_normp(const GemmPlan& pl, dim3 grid, size_t lds, hipStream_t st, const GemmArgs& a) {
-    switch (pl.TN * 10 + pl.WK) {
-        case 44: return launch_one<4, 4, ACT, true, false, 1, true>(grid, lds, st, a);
-        case 42: return launch_one<4, 2, ACT, true, false, 1, true>(grid, lds, st, a);
-        case 34: return launch_one<3, 4, ACT, true, false, 1, true>(grid, lds, st, a);
-        case 32: return launch_one<3, 2, ACT, true, false, 1, true>(grid, lds, st, a);
-        case 24: return launch_one<2, 4, ACT, true, false, 1, true>(grid, lds, st, a);
-        default: return launch_one<2, 2, ACT, true, false, 1, true>(grid, lds, st, a);
-    }
 }
 template <int TN, int WK, int ACT, bool G64, bool PERM>
 static int launch_variant(int mr, dim3 grid, size_t lds, hipStream_t st, const GemmArgs& a) {
@@ -657,8 +640,7 @@ static int launch_wide_one(dim3 grid, hipStream_t st, const GemmArgs& a) {
 
 static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const void* bias, const int32_t* perm,
                        void* out, int64_t ldo, int64_t M, int64_t K, int64_t N, int64_t groups, int act, float* slabs,
-                       int partial, const GemmPlan& pl, hipStream_t st, const RopeEpi* rope = nullptr,
-                       const gsync::NormPhase* norm = nullptr, gsync::GridBar* bar = nullptr) {
+                       int partial, const GemmPlan& pl, hipStream_t st, const RopeEpi* rope = nullptr) {
     PrepLayout p = prep_layout(K, N, groups);
     const int64_t mslabs = cdiv64(M, 32 * pl.MR);  // passes over the weights
     const int64_t gs = K / groups;
@@ -685,7 +667,6 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
     a.slabs = slabs;
     a.partial = partial;
     a.spg_shift = 30;
-    a.err = nullptr;
     a.positions = a.slots = nullptr;
     a.cosb = a.sinb = nullptr;
     a.kpool = a.vpool = nullptr;
@@ -703,8 +684,6 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
     }
     if (groups > 1 && group64)
         for (a.spg_shift = 0; (1 << a.spg_shift) < spg; ++a.spg_shift) {}
-    a.norm = gsync::NormPhase{};
-    a.bar = nullptr;
     if (ldx == TGIS_LD_FRAGMENTS) {
         // activation in fragment order: the kernel of gptq_wide_body.h; `pl` carries its plan as TN = CT, S (callers use
         // wide_plan_as_gemm_plan); checked by the caller: wide_serves(), act in {0, 2, 3}, no permutation
@@ -732,15 +711,6 @@ static int launch_gptq(const void* x, int64_t ldx, const void* prepared, const v
     }
     dim3 grid((unsigned)cdiv64(p.NT, pl.TN), (unsigned)pl.S, (unsigned)mslabs);
     const size_t lds = (size_t)pl.WK * 2 * 32 * pl.MR * RS * sizeof(f16) + 64;  // x buffers + arrival counters
-    if (norm) {  // checked by the caller: act 2 / 3, group64, no permutation, <= 32 rows, S == 1, rows <= grid.x <= CUs
-        a.norm = *norm;
-        a.bar = bar;
-        a.err = &bar->err;
-        int rc_ = act == 3 ? launch_normp<3>(pl, grid, lds, st, a) : launch_normp<2>(pl, grid, lds, st, a);
-        if (rc_ != TGIS_OK) return rc_;
-        TGIS_CHECK_LAUNCH();
-        return TGIS_OK;
-    }
 #define TGIS_LAUNCH_GEMM(T, W, A, G, P)                                                        \
     do {                                                                                       \
         int rc_ = launch_variant<T, W, A, G, P>(pl.MR, grid, lds, st, a);                      \

@@ -1,19 +1,12 @@
-// The int4 GPTQ streaming GEMM as a device function, shared by the stand-alone kernel (gptq.hip) and the persistent
-// decode-tail kernel (decode_tail.hip), plus the launch planning both use.
-//
-// TAIL = false: one workgroup = one unit, block-wide s_barrier, plain loads and stores (the kernel of round 1).
-// TAIL = true : the unit runs inside a persistent workgroup, possibly next to waves that take no part (so the unit's
-//   waves synchronise through an LDS counter instead of s_barrier), and its input / output travel between workgroups
-//   INSIDE one launch: the activation is read with sc1 (L1-bypassing) loads and the results leave as 16-byte sc1
-//   (write-through) stores assembled through LDS — the {sc1 stores, drained vmcnt, flag, sc1 loads} form of
-//   MI355X_MICROARCH.md (inter-workgroup visibility); the grid barrier that orders them lives in decode_tail.hip.
+// The int4 GPTQ streaming GEMM as a device function (one workgroup = one unit) plus its launch planning; the kernel that
+// runs it is in gptq.hip.  (Rounds 2 - 5 also ran this unit inside a persistent "decode tail" launch and with an add +
+// RMSNorm phase in front of it — both measured slower than separate launches and removed in round 6: experiments/README.md.)
 #pragma once
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
 #include "common.h"
 #include "kv_layout.h"
-#include "grid_sync.h"
 
 namespace gptq {
 
@@ -77,7 +70,6 @@ struct GemmArgs {
     float* slabs;  // [Mslabs][S][32][NT*32] f32 partial sums (S > 1 or partial mode)
     int partial;   // 1: always leave fp32 slabs (deferred reduce), never write `out`
     int spg_shift; // GROUP64: log2(k64-steps per group) (30 when there is a single group)
-    unsigned* err; // decode tail: word that receives a code when a bounded spin gives up (nullptr otherwise)
     // ACT == 3 (rope image): the epilogue rotates q / k heads and writes k / v into their cache pages; `out` is the q tensor
     const int32_t* positions;  // [M]
     const int32_t* slots;      // [M] page * 32 + token
@@ -86,12 +78,7 @@ struct GemmArgs {
     f16* kpool;                // [pages][rHkv][32 * rD] in the K page layout of kv_layout.h
     f16* vpool;
     int rH, rHkv, rD;
-    // NORMP units (stand-alone kernel, ACT 2 / 3): the add + RMSNorm in front of this GEMM runs as its first phase — row r by
-    // workgroup r — and a grid barrier hands its output (norm.y == x) to every workgroup (grid_sync.h)
-    gsync::NormPhase norm;
-    gsync::GridBar* bar;
 };
-constexpr unsigned TAIL_SPIN_LIMIT = 1u << 24;
 
 #ifdef TGIS_TRACE
 static __device__ long long* g_trace = nullptr;  // [blocks][16 waves][32 stamps] of s_memtime (debug builds only)
@@ -131,40 +118,19 @@ constexpr int RS = KC + 8;  // LDS row stride in halves (+16 B -> conflict-free 
 // MR = 32-row blocks of x per pass: 1 (M <= 32), or 2 for larger decode batches — the wave dequantises each fragment
 // once and feeds it to two MFMAs, instead of streaming and dequantising the weights again for rows 32..63.  MR = 2 needs
 // WK = 2 (the x chunk buffers double).
-// LDS of one unit: the x chunk buffers of the WK k-parts (reused by the k-part reduction and, TAIL, by the output
-// assembly), then one control line: k-part arrival counters and (TAIL) the unit barrier counter.
-constexpr int TAIL_XREGION = 4 * 2 * 32 * RS * (int)sizeof(f16);  // WK = 4, MR = 1: the largest unit of the tail
-constexpr int TAIL_CTRL = TAIL_XREGION;                           // int[0..7] k-part counters, int[8] unit barrier
-constexpr int TAIL_LDS = TAIL_XREGION + 256;
+// LDS of one unit: the x chunk buffers of the WK k-parts (reused by the k-part reduction), then the k-part arrival counters.
 
 typedef __attribute__((address_space(3))) int lds_int;  // explicit LDS pointer: a generic one costs vmcnt(0) waits
 
-// unit barriers a unit executes (every wave of the persistent workgroup advances its copy of the counter by this)
-__host__ __device__ constexpr int unit_barriers(int WK) { return WK > 1 ? 4 : 3; }
-
-// The weights a wave has in flight: RING one-KiB loads and (GROUP64) the {scale, zero} words of their k64-steps.
-// Stand-alone kernel: RING = 4 (one chunk; a two-chunk ring measured ~1 us SLOWER there on every cfg3 shape: the first
-// barrier waits for twice the prologue loads to issue).  Decode tail: RING = 8, filled BEFORE the grid barrier that
-// precedes the phase (the weights do not depend on the activation), so they stream while the workgroup waits.
-template <int RING>
-struct WeightRing {
-    u32x4 wq[RING];
-    uint32_t szr[RING];
-};
-enum { UNIT_FULL = 0, UNIT_PREFETCH = 1, UNIT_RUN = 2 };  // MODE: whole unit / only fill the ring / run on a filled ring
-
-// `ub_base` (TAIL): value of the unit-barrier counter when the unit starts; every wave of the workgroup tracks it.
-template <int TN, int WK, int ACT, bool GROUP64, bool PERM, int MR, bool TAIL, int RING, int MODE, bool NORMP = false>
+// A wave keeps RING = 4 one-KiB weight loads (one chunk) and the {scale, zero} words of their k64-steps in flight; a
+// two-chunk ring measured ~1 us SLOWER on every cfg3 shape (the first barrier waits for twice the prologue loads to issue).
+template <int TN, int WK, int ACT, bool GROUP64, bool PERM, int MR>
 __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg, const int split, const int mslab,
-                                               unsigned char* smem, const int ub_base, WeightRing<RING>& ring) {
+                                               unsigned char* smem) {
     static_assert(MR == 1 || WK == 2, "64-row passes need the LDS of two k-parts");
-    static_assert(!TAIL || (MR == 1 && !PERM && ACT != 1 && ACT != 3), "the decode tail runs 32-row, un-permuted units");
+    static_assert(WK > 1, "the finish below exchanges k-parts");
     static_assert(ACT != 3 || !PERM, "the rope epilogue is a decode form (<= 64 rows, no act-order)");
-    static_assert(!NORMP || (!TAIL && !PERM && GROUP64 && MR == 1 && (ACT == 2 || ACT == 3) && MODE == UNIT_FULL),
-                  "the norm phase exists in front of the 32-row gate_up and qkv units of the stand-alone kernel");
-    static_assert(RING == 4 || RING == 8, "one or two chunks of weights in flight");
-    static_assert(MODE == UNIT_FULL || GROUP64, "a pre-filled ring carries the scales of GROUP64 images");
-    constexpr int NWAVES = TN * WK;
+    constexpr int RING = 4;
     constexpr int XR = 32 * MR;                 // x rows per pass
     constexpr int GT = 64 * TN;                 // threads of one k-part group
     constexpr int NJ = (XR * 32 + GT - 1) / GT;  // 16-byte x pieces per thread per chunk (XR rows x 32 pieces per chunk)
@@ -176,11 +142,11 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
     TRACE(0);
     TRACE_RT(14);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Stand-alone kernel: k-part = w % WK, so that every k-part owns waves of every age.  A CU serves its older waves first
+    // k-part = w % WK, so that every k-part owns waves of every age.  A CU serves its older waves first
     // (issue and memory return): with k-part = w / TN the k-part of the youngest waves finished 2.5 us (gate_up) after the
     // k-part of the oldest ones, and everybody waited for it; the per-chunk sync of a mixed k-part holds its old waves back
     // instead, which is what lets the young ones catch up.
-    const int wn = TAIL ? w % TN : w / WK, wk = TAIL ? w / TN : w % WK, ltid = wn * 64 + lane;
+    const int wn = w / WK, wk = w % WK, ltid = wn * 64 + lane;
     f16* xs = reinterpret_cast<f16*>(smem) + wk * (2 * XR * RS);  // this k-part's [2][XR][RS]
     const int m0 = mslab * XR;
     const int mrows = min(XR, a.M - m0);
@@ -212,17 +178,8 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
         return __builtin_nontemporal_load((const GLOBAL_AS u32x4*)(p + woff));
     };
     const uint32_t* szp = reinterpret_cast<const uint32_t*>(sztile + szoff);
-    u32x4 (&wq)[RING] = ring.wq;
-    uint32_t (&szr)[RING] = ring.szr;
-    if (MODE == UNIT_PREFETCH) {
-        // Only the loads that do not depend on the activation, into registers.  Nothing else is touched — in
-        // particular no LDS: waves that idle through the previous unit get here while it is still running.
-#pragma unroll
-        for (int s = 0; s < RING; ++s) szr[s] = sz_at(s);
-#pragma unroll
-        for (int s = 0; s < RING; ++s) wq[s] = w_at(s);
-        return;
-    }
+    u32x4 wq[RING];
+    uint32_t szr[RING];
 
     // ACT 3: cache slot and rotary position of the rows this wave will finish (see the distributed epilogue)
     int32_t rpos[ACT == 3 ? MR : 1][ACT == 3 ? 16 / WK : 1], rslot[ACT == 3 ? MR : 1][ACT == 3 ? 16 / WK : 1];
@@ -247,8 +204,6 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
     uint32_t rowoff[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) rowoff[j] = (uint32_t)(min(srow + RSTEP * j, mrows - 1) * (int)a.ldx * 2);
-    // TAIL: x was written by other workgroups of this launch -> sc1 loads (a CU's L1 is never refreshed by other CUs)
-    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(xbase), 0, 0x7FFFFFFF, 0x00020000);
     auto stage_load = [&](int chunk) {
         const int kc = min(k0 + chunk * KC + scol, a.K - 8);
         const char* xb = reinterpret_cast<const char*>(xbase);
@@ -256,9 +211,6 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             f16x8 v, u;
-            if (TAIL || NORMP) {  // x was written by other workgroups of THIS launch: L1-bypassing loads
-                v = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, rowoff[j] + (uint32_t)kc * 2, 0, 16));
-            } else
             if (!PERM) {
                 const uint32_t off = rowoff[j] + (uint32_t)kc * 2;
                 v = *(const GLOBAL_AS f16x8*)(xb + off);
@@ -313,79 +265,31 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
     // Per-k-part arrival counters (monotonic): only the TN waves that share an x buffer synchronise per chunk.  A
     // block-wide s_barrier would park every wave until the slowest of all TN*WK has finished its chunk (the SIMD
     // arbiter serves its oldest wave first, so a third of the loop time went to that skew).
-    volatile lds_int* sync_cnt =
-        (volatile lds_int*)(smem + (TAIL ? (size_t)TAIL_CTRL : (size_t)WK * 2 * XR * RS * sizeof(f16))) + wk;
-    volatile lds_int* ubar = (volatile lds_int*)(smem + TAIL_CTRL) + 8;
-    int ub_target = ub_base;
-    // all NWAVES waves of the unit meet here; the LDS traffic a wave issued before is complete when it arrives
+    volatile lds_int* sync_cnt = (volatile lds_int*)(smem + (size_t)WK * 2 * XR * RS * sizeof(f16)) + wk;
+    // all waves of the unit meet here; the LDS traffic a wave issued before is complete when it arrives
     auto unit_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!TAIL) {
-            __builtin_amdgcn_s_barrier();
-        } else {
-            ub_target += NWAVES;
-            if (lane == 0) __hip_atomic_fetch_add((lds_int*)ubar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            for (unsigned spins = 0; __builtin_amdgcn_readfirstlane(*ubar) < ub_target; ++spins) {
-                __builtin_amdgcn_s_sleep(1);
-                if (spins > TAIL_SPIN_LIMIT) {  // never hang the device: flag the launch as failed and go on
-                    if (a.err && lane == 0) __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-            asm volatile("" ::: "memory");
-        }
+        __builtin_amdgcn_s_barrier();
     };
     if (wn == 0 && lane == 0) *sync_cnt = 0;
     // Issue order matters: a wave's loads return in order, so the (L2-resident) first x chunk goes out before the
     // HBM weight stream it would otherwise queue behind; then the small scale loads, then the ring of weights.
-    if (NORMP) {
-        // Phase 0: workgroup r normalises row r (all its threads), everybody meets at the grid barrier, and the weight ring
-        // of this unit — which does not depend on x — is requested between arriving and waiting, so that the first-data
-        // latency of the GEMM runs under the norm rows and the barrier instead of after them.
-        gsync::BarCtx bc = gsync::bar_init(a.bar);
-        const int blk = blockIdx.x;  // NORMP grids are one-dimensional (S == 1, one 32-row pass)
-        if (blk < a.norm.rows) gsync::norm_row<f16, 4>(a.norm, blk, reinterpret_cast<float*>(smem), NWAVES * 64);
-        gsync::grid_sync(a.bar, bc, [&]() {
-#pragma unroll
-            for (int s = 0; s < RING; ++s) szr[s] = sz_at(s);
-#pragma unroll
-            for (int s = 0; s < RING; ++s) wq[s] = w_at(s);
-        });
-        stage_load(0);
-        unit_barrier();
-    } else {
     stage_load(0);
-    // Stand-alone kernel: the block-wide barrier that publishes the zeroed counters sits HERE, between the x requests and
-    // the weight requests of every wave.  A CU serves its waves' requests in arrival order: without it a later wave's
-    // first x chunk queues behind the HBM weight requests of the waves that started before it, and the first chunk was
-    // staged only when the whole first ring had arrived (3.1 us after entry for gate_up); with it every x request of the
-    // block is in front of every weight request.
-    if (!TAIL) unit_barrier();
-    if (MODE == UNIT_FULL) {
+    // The block-wide barrier that publishes the zeroed counters sits HERE, between the x requests and the weight requests
+    // of every wave.  A CU serves its waves' requests in arrival order: without it a later wave's first x chunk queues
+    // behind the HBM weight requests of the waves that started before it, and the first chunk was staged only when the
+    // whole first ring had arrived (3.1 us after entry for gate_up); with it every x request of the block is in front of
+    // every weight request.  From here on each k-part group paces itself.
+    unit_barrier();
 #pragma unroll
-        for (int s = 0; s < RING; ++s)
-            if (GROUP64) szr[s] = sz_at(s);
+    for (int s = 0; s < RING; ++s)
+        if (GROUP64) szr[s] = sz_at(s);
 #pragma unroll
-        for (int s = 0; s < RING; ++s) wq[s] = w_at(s);
-    }
-    // the only block-wide barrier before the reduction publishes the zeroed counters; it does not wait for the loads
-    // above, and from here on each k-part group paces itself
-    if (TAIL) unit_barrier();
-    }
+    for (int s = 0; s < RING; ++s) wq[s] = w_at(s);
     auto group_sync = [&](int target) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add((lds_int*)sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!TAIL) {
-            while (__builtin_amdgcn_readfirstlane(*sync_cnt) < target) __builtin_amdgcn_s_sleep(1);
-        } else {
-            for (unsigned spins = 0; __builtin_amdgcn_readfirstlane(*sync_cnt) < target; ++spins) {
-                __builtin_amdgcn_s_sleep(1);
-                if (spins > TAIL_SPIN_LIMIT) {
-                    if (a.err && lane == 0) __hip_atomic_store(a.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
+        while (__builtin_amdgcn_readfirstlane(*sync_cnt) < target) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
     };
     stage_store(0);
@@ -462,33 +366,12 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
         TRACE(4 + 2 * min(chunk, 3));
     };
     using I0 = std::integral_constant<int, 0>;
-    using I4 = std::integral_constant<int, 4>;
     using Y = std::true_type;
     using N = std::false_type;
-    if (RING == 4) {
-        for (int chunk = 0; chunk + 1 < nchunks; ++chunk) chunk_body(chunk, I0{}, Y{}, Y{});
-        chunk_body(nchunks - 1, I0{}, N{}, N{});
-    } else {
-        // two chunks in the ring: chunk c sits in slots 4 (c & 1) ..; pairs while both halves still refill
-        int chunk = 0;
-        for (; chunk + 3 < nchunks; chunk += 2) {
-            chunk_body(chunk, I0{}, Y{}, Y{});
-            chunk_body(chunk + 1, I4{}, Y{}, Y{});
-        }
-        const int left = nchunks - chunk;  // 1, 2 or 3 (wave-uniform)
-        if (left == 3) {
-            chunk_body(chunk, I0{}, Y{}, Y{});
-            chunk_body(chunk + 1, I4{}, Y{}, N{});
-            chunk_body(chunk + 2, I0{}, N{}, N{});
-        } else if (left == 2) {
-            chunk_body(chunk, I0{}, Y{}, N{});
-            chunk_body(chunk + 1, I4{}, N{}, N{});
-        } else {
-            chunk_body(chunk, I0{}, N{}, N{});
-        }
-    }
+    for (int chunk = 0; chunk + 1 < nchunks; ++chunk) chunk_body(chunk, I0{}, Y{}, Y{});
+    chunk_body(nchunks - 1, I0{}, N{}, N{});
     TRACE(9);
-    // Non-TAIL units finish DISTRIBUTED (below): wave (wn, wk) ends up with accumulator registers [wk NR, (wk + 1) NR) of
+    // The unit finishes DISTRIBUTED (below): wave (wn, wk) ends up with accumulator registers [wk NR, (wk + 1) NR) of
     // its tile, i.e. NR of the 16 row groups.  ACT 3: it asks for those rows' cos / sin entries now (the positions were
     // loaded at entry), so that the round trip runs under the k-part exchange.
     constexpr int NR = 16 / WK;
@@ -511,12 +394,12 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
     f32x16 acc[MR];
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) acc[mr] = NACC == 2 ? accs[mr][0] + accs[mr][1] : accs[mr][0];
-    // ---- stand-alone kernel: distributed finish ---------------------------------------------------------------------
+    // ---- distributed finish ------------------------------------------------------------------------------------------
     // Every wave (k-part 0 included) leaves its partial sums in LDS; wave (wn, wk) then sums the WK k-parts of registers
     // [wk NR, (wk + 1) NR) of tile wn in the fixed order 0..WK-1 (bit-identical to the reducer-wave form) and runs the
     // epilogue for those rows only: the loads, the arithmetic and the scattered stores of the tail are spread over all
     // waves of the block instead of a quarter of them.
-    if (!TAIL && WK > 1) {
+    {
         float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][MR][64 lanes][16]; the x buffers are dead now
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
@@ -636,160 +519,6 @@ __device__ __forceinline__ void gptq_gemm_unit(const GemmArgs& a, const int ntg,
             }
         }
         return;
-    }
-
-    // ---- decode tail: sum the WK k-parts through LDS in reducer waves (fixed order => deterministic) -----------------
-    if (WK > 1) {
-        float* red = reinterpret_cast<float*>(smem);  // [WK][TN tiles][MR][64 lanes][16]; the x buffers are dead now
-        if (wk > 0) {
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr) {
-                float* dst = red + ((((wk * TN + wn) * MR + mr) * 64 + lane) << 4);
-#pragma unroll
-                for (int r = 0; r < 16; r += 4)
-                    *reinterpret_cast<f32x4*>(dst + r) = f32x4{acc[mr][r], acc[mr][r + 1], acc[mr][r + 2], acc[mr][r + 3]};
-            }
-        }
-        unit_barrier();
-        TRACE(11);
-        if (wk > 0) {
-            if (TAIL) unit_barrier();  // the unit's LDS is free again only when its reducer waves are through
-            return;
-        }
-#pragma unroll
-        for (int k2 = 1; k2 < WK; ++k2)
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr) {
-                const float* src = red + ((((k2 * TN + wn) * MR + mr) * 64 + lane) << 4);
-#pragma unroll
-                for (int r = 0; r < 16; r += 4) {
-                    f32x4 t = *reinterpret_cast<const f32x4*>(src + r);
-                    acc[mr][r] += t[0];
-                    acc[mr][r + 1] += t[1];
-                    acc[mr][r + 2] += t[2];
-                    acc[mr][r + 3] += t[3];
-                }
-            }
-    }
-
-    // ---- epilogue: lane holds out[m = 32 mr + (r&3)+8(r>>2)+4(lane>>5)][n = nt*32 + (lane&31)] -------
-    TRACE(12);
-    TRACE_RT(15);
-    if (TAIL) {
-        // Results leave as 16-byte sc1 stores: the 32 x 32 (ACT 2: 32 x 16) tile is laid out row-major in a private LDS
-        // scratch (beyond the k-part reduction area) and every lane then moves whole 16-byte row pieces.
-        if (nt_raw < a.NT) {
-            unsigned char* scr = smem + NWAVES * 4096 + wn * 4096;
-            if (ACT == 2) {
-                const int c = lane & 31;
-                const int half = a.N >> 1;
-                const int j = nt * 16 + (c & 15);
-                const int nsrc = (c < 16) ? j : half + j;
-                const float bv = a.bias ? (float)a.bias[nsrc] : 0.f;
-                f16* t = reinterpret_cast<f16*>(scr);  // [32][16]
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float mine = (float)(f16)(acc[0][r] + bv);
-                    const float other = __shfl_xor(mine, 16, 64);
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (c < 16) {
-                        float sl = mine / (1.f + __expf(-mine));
-                        t[m * 16 + c] = (f16)((float)(f16)sl * other);
-                    }
-                }
-                __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7FFFFFFF, 0x00020000);
-                const int row = lane >> 1, h8 = (lane & 1) * 8;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(t + row * 16 + h8);
-                if (row < mrows)
-                    __builtin_amdgcn_raw_buffer_store_b128(
-                        v, orsrc, (uint32_t)(((int64_t)(m0 + row) * a.ldo + nt * 16 + h8) * 2), 0, 16);
-            } else if (a.S == 1 && !a.partial) {
-                const int c = lane & 31;
-                const float bv = a.bias ? (float)a.bias[nt * 32 + c] : 0.f;
-                f16* t = reinterpret_cast<f16*>(scr);  // [32][32]
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    t[m * 32 + c] = (f16)(acc[0][r] + bv);
-                }
-                __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7FFFFFFF, 0x00020000);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int p = i * 64 + lane, row = p >> 2, q8 = (p & 3) * 8;
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(t + row * 32 + q8);
-                    if (row < mrows)
-                        __builtin_amdgcn_raw_buffer_store_b128(
-                            v, orsrc, (uint32_t)(((int64_t)(m0 + row) * a.ldo + nt * 32 + q8) * 2), 0, 16);
-                }
-            } else {
-                const int c = lane & 31;
-                float* t = reinterpret_cast<float*>(scr);  // [32][32]
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    t[m * 32 + c] = acc[0][r];
-                }
-                __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, 0x7FFFFFFF, 0x00020000);
-                const int64_t np = (int64_t)a.NT * 32;
-                const int64_t base = ((int64_t)(mslab * a.S + split) * 32) * np + nt * 32;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int p = i * 64 + lane, row = p >> 3, c4 = (p & 7) * 4;
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(t + row * 32 + c4);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, srsrc, (uint32_t)((base + row * np + c4) * 4), 0, 16);
-                }
-            }
-        }
-        unit_barrier();  // the unit's LDS may be reused from here on
-        return;
-    }
-    if (nt_raw >= a.NT) return;
-    const int n = nt * 32 + (lane & 31);
-    if (ACT == 2) {
-        // columns are interleaved gate/up pairs (col_src flags bit 0): lanes c < 16 hold gate column j = 16 nt + c,
-        // lanes c + 16 the matching up column.  out[m][j] = f16(f16(silu(f16 gate)) * f16 up), the rounding
-        // sequence of the reference's eager ops (flash_llama_modeling.py:332-335).  Host guarantees S == 1.
-        const int c = lane & 31;
-        const int half = a.N >> 1;
-        const int j = nt * 16 + (c & 15);
-        const int nsrc = (c < 16) ? j : half + j;
-        const float bv = (a.bias && j < half) ? (float)a.bias[nsrc] : 0.f;
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float mine = (float)(f16)(acc[mr][r] + bv);
-                const float other = __shfl_xor(mine, 16, 64);
-                const int m = mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (c < 16 && j < half && m < mrows) {
-                    float sl = mine / (1.f + __expf(-mine));
-                    a.out[(int64_t)(m0 + m) * a.ldo + j] = (f16)((float)(f16)sl * other);
-                }
-            }
-        return;
-    }
-    if (a.S == 1 && !a.partial) {
-        const float bv = (a.bias && n < a.N) ? (float)a.bias[n] : 0.f;
-        if (n < a.N) {
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (m < mrows) a.out[(int64_t)(m0 + m) * a.ldo + n] = (f16)(acc[mr][r] + bv);
-                }
-        }
-    } else {
-        // slabs are indexed in 32-row units: this pass owns units mslab*MR .. mslab*MR + MR-1
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr) {
-            float* sl = a.slabs + ((int64_t)((mslab * MR + mr) * a.S + split) * 32) * (a.NT * 32) + n;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                sl[(int64_t)m * (a.NT * 32)] = acc[mr][r];
-            }
-        }
     }
 }
 

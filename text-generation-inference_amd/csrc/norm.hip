@@ -5,7 +5,6 @@
 //   y   = norm(res) * weight (+ bias)   [statistics in fp32 from the fp32 sum, one rounding at the end]
 // One 256-thread workgroup per row, 16-byte loads, row cached in registers (hidden <= 16384).
 #include "common.h"
-#include "grid_sync.h"
 
 namespace {
 
@@ -37,26 +36,6 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
     constexpr int MAXV = MAX_HIDDEN / (NT * 8);
     __shared__ float sh[NT / 64];
     const int64_t row = blockIdx.x;
-    if (RMS) {
-        // the RMS form is one function shared with the GEMM kernels that run the norm as their first phase
-        // (grid_sync.h): identical arithmetic by construction
-        gsync::NormPhase p;
-        p.slabs = PARTIAL ? slabs : nullptr;
-        p.S = S;
-        p.slab_ld = slab_ld;
-        p.xbias = xbias;
-        p.x = x;
-        p.residual = residual;
-        p.weight = weight;
-        p.y = y;
-        p.res_out = res_out;
-        p.rows = gridDim.x;
-        p.hidden = hidden;
-        p.eps = eps;
-        p.y_frag = y_frag;
-        gsync::norm_row<T, MAXV, false>(p, (int)row, sh, NT);
-        return;
-    }
     const T* xr = PARTIAL ? nullptr : x + row * hidden;
     const T* rr = residual ? residual + row * hidden : nullptr;
     float v[MAXV][8];
@@ -69,7 +48,9 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
         if (c < nchunk) {
             wvs[it] = ld16<V8>(weight + c * 8);
             if (bias) bvs[it] = ld16<V8>(bias + c * 8);
-            // (round 5: residual and GEMM bias requested in front of the slabs, as in gsync::norm_row)
+            // Round 5: the residual and the bias of the GEMM before are requested HERE, in front of the slabs.  Behind them (in
+            // their own basic blocks, after the waits of the slab sum) they were a second and a third dependent round trip to
+            // memory in a kernel that is nothing but one round trip.
             V8 b, bv;
             if (rr) b = ld16<V8>(rr + c * 8);
             if (PARTIAL && xbias) bv = ld16<V8>(xbias + c * 8);
@@ -146,7 +127,8 @@ __global__ __launch_bounds__(NT) void norm_kernel(const T* x, const T* residual,
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = from_f32<T>((v[it][e] - mean) * rstd * to_f32(wv[e]));
             }
-            st16(y + row * hidden + c * 8, o);
+            // y_frag (RMSNorm in front of an int4 decode GEMM): 32-row fragment order, xf_off in common.h
+            st16(y + (y_frag ? xf_off(row, c * 8, hidden) : row * hidden + c * 8), o);
         }
     }
 }

@@ -74,8 +74,8 @@ class KVArgs:
     fresh_prefill: bool = False        # every sequence starts at cache position 0: page-wise cache writes
 
 
-# The persistent decode tail, the rope-in-attention launch and the norm-as-a-GEMM-phase launches of rounds 2 and 3 (all
-# measured slower than the launches they replace) live in experiments/, not on this path.
+# (The persistent decode tail, the rope-in-attention launch and the norm-as-a-GEMM-phase launches of rounds 2 and 3 were all
+# measured slower than the launches they replace: experiments/README.md is their ledger.)
 
 
 def frag_rows(linear, rows: int, kv: "KVArgs", act: int = 0) -> bool:
