@@ -178,38 +178,6 @@ int64_t tgis_dense_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
 int tgis_dense_gemm(const void* x, int64_t ldx, const void* prepared, const void* bias, void* out,
                     int64_t ldo, int64_t M, int64_t K, int64_t N, int dtype, int out_f32, int act,
                     void* workspace, int64_t workspace_bytes, void* stream);
-/* ---- the add + RMSNorm around a decode GEMM, folded into the GEMMs (round 6) -----------------------------------------
- * The reference runs `dropout_add_ln_fwd` (LlamaRMSNorm.forward, flash_llama_modeling.py:113-152) as a launch of its own in
- * front of qkv and of gate_up, and adds the residual there.  For decode batches of up to 32 rows both halves of that launch
- * fit into the GEMMs around it, and a Llama layer is five launches instead of seven:
- *   producer (o_proj, down_proj; act 0):  out = T(T(x @ W^T + bias) + out_residual)       — the residual stream itself;
- *   consumer (qkv + rotary, gate_up + SiLU, lm_head; norm_weight):  the operand is RMS-normalised while it is staged —
- *     h = x (or T(x + x_residual), which is also written to residual_out: tensor-parallel ranks, whose producer's output
- *     passes an all-reduce first), A = T(h * norm_weight) goes to the MFMAs, every row's sum of h^2 is collected from the
- *     chunks the block stages anyway, and rstd(row) = rsqrt(sum / K + eps) scales the fp32 sums before bias, rotation or
- *     SiLU * up.
- * Numerics: the statistics come from the ROUNDED residual stream h (as the reference's own torch branch for hidden sizes
- * above 8192, flash_llama_modeling.py:112-128; its dropout_layer_norm branch takes them from the unrounded fp32 sum) and
- * rstd is applied to the fp32 accumulator instead of to every operand element before it is rounded: within the tolerance
- * tests/test_fold_gpu.py states, not bit-identical to tgis_rmsnorm_residual + GEMM.
- * Unsplit plans only; tgis_dense_fold_ok says whether the folded launch exists for a shape (1 <= M <= 32, K >= 1024,
- * act 0 / 2 / 3 = plain, SiLU * up image, rope image). */
-typedef struct tgis_fold {
-    const void* norm_weight;   /* [K] model dtype, or NULL (producer) */
-    float eps;
-    const void* x_residual;    /* [M, K] row stride ldx, or NULL: h = T(x + x_residual) (needs norm_weight, residual_out) */
-    void* residual_out;        /* [M, K] contiguous: receives h when x_residual is given */
-    const void* out_residual;  /* [M, N] row stride ldo, or NULL: added to the rounded output (act 0, model-dtype output) */
-} tgis_fold;
-int tgis_dense_fold_ok(int64_t M, int64_t K, int64_t N, int act, int with_norm);
-int tgis_dense_gemm_fold(const void* x, int64_t ldx, const void* prepared, const void* bias, void* out, int64_t ldo,
-                         int64_t M, int64_t K, int64_t N, int dtype, int out_f32, int act, const tgis_fold* fold,
-                         void* stream);
-int tgis_dense_gemm_rope_fold(const void* x, int64_t ldx, const void* prepared, const void* bias, const int32_t* positions,
-                              const int32_t* slots, const void* cos, const void* sin, void* q_out, int64_t ldq,
-                              void* k_pool, void* v_pool, int64_t M, int64_t K, int64_t N, int64_t H, int64_t Hkv,
-                              int64_t D, int dtype, const tgis_fold* fold, void* stream);
-
 /* Deferred split-K, as tgis_gptq_gemm_f16_partial: the fp32 partial sums [ceil(M/32)][num_slabs][32][slab_ld] are
  * left for the consumer kernel (tgis_rmsnorm_residual_partial / tgis_rope_kv_write_partial), which adds the bias. */
 int64_t tgis_dense_gemm_partial_bytes(int64_t M, int64_t K, int64_t N);

@@ -32,17 +32,6 @@ struct DenseArgs {
     void* kpool;               // [pages][rHkv][32 * rD] in the K page layout of kv_layout.h
     void* vpool;
     int rH, rHkv, rD;
-    // The add + RMSNorm around a decode GEMM folded into it (round 6, tgis_fold in include/tgis_hip.h):
-    // NORM units — the consumer side: x is RMS-normalised while it is staged.  A = T(h * w) goes to LDS, the rows' sums of
-    //   h^2 are collected from the chunks every k-part stages anyway, and rstd(row) scales the finished fp32 sums in the
-    //   epilogue (a per-row scale commutes with the GEMM, the rotation and SiLU * up read the scaled sum).  Needs the whole
-    //   k range in one block (S == 1).  (tgis_fold::x_residual — the residual add on the consumer side, for ranks whose
-    //   producer's output passes an all-reduce — exists for the int4 kernels only: gptq_wide_body.h.)
-    // `res` — the producer side: out = T(T(sum + bias) + res) where the plain epilogue stores (S == 1), i.e. the residual
-    //   add that the reference's NEXT fused add + RMSNorm would make (flash_llama_modeling.py:132-152).
-    const void* norm_w;  // [K] model dtype
-    float eps;
-    const void* res;     // [M, N] row stride ldo, or nullptr
 };
 
 constexpr int DKC = 256;      // k per LDS chunk (4 k64-steps)
@@ -70,16 +59,11 @@ __device__ __forceinline__ T finish_out(float v, int gelu) {
 //   out[m][j] = T(T(silu(T gate)) * T up), [rows, N/2] — once per element, where ACT = 1 recomputes the SiLU in every
 //   column block of the consumer.  Needs S == 1 (the planner guarantees it).
 // MR = 32-row blocks of x per pass (2 for M > 32: every weight fragment then feeds two MFMAs; needs WK = 2).
-// NORM: see DenseArgs.  DR = k64-steps of weights in flight per wave: DRING where the grid covers the chip; 4 for the
-// narrow unsplit grids of the folded layer (64 - 128 blocks on 256 CUs: HBM is far from busy and a block's rate is its
-// bytes in flight over the memory latency — a one-tile block with 32 KB in flight takes in ~50 GB/s).
-template <typename T, int TN, int WK, int ACT, int MR, bool NORM = false, int DR = DRING>
+template <typename T, int TN, int WK, int ACT, int MR>
 __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int ntg, const int split, const int mslab,
                                                 unsigned char* smem) {
     static_assert(MR == 1 || WK == 2, "64-row passes need the LDS of two k-parts");
     static_assert(WK > 1, "the finish below exchanges k-parts");
-    static_assert(DR == 2 || DR == 4, "the ring is indexed with a mask and refilled within a four-step chunk");
-    static_assert(!NORM || ACT != 1, "the folded norm stages a plain operand");
     using V8 = typename VecT<T>::x8;
     constexpr int XR = 32 * MR;
     constexpr int GT = 64 * TN;
@@ -102,7 +86,7 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
 
     const char* wtile = reinterpret_cast<const char*>(a.prep) + (int64_t)nt * a.KS * 4096;
     const uint32_t woff = lane * 16;
-    V8 wq[DR][4];  // the weights a wave has in flight
+    V8 wq[DRING][4];  // the weights a wave has in flight
     auto w_load = [&](int step, V8* dst) {
         const char* p = wtile + (int64_t)min(ks0 + step, ks_clamp) * 4096;
         PIN_SGPR(p);  // wave-uniform base in SGPRs: (sgpr base + lane offset) addressing
@@ -129,12 +113,6 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
     const T* xbase = reinterpret_cast<const T*>(a.x) + (int64_t)m0 * a.ldx;
     const int srow = ltid >> 5, scol = (ltid & 31) * 8;
     V8 xg[NJ], xu[NJ];
-    V8 nw;                           // NORM: the norm weights of the chunk being staged
-    float ssq[NORM ? NJ : 1];        // NORM: this thread's share of sum(h^2) of its rows
-    if (NORM) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) ssq[j] = 0.f;
-    }
     bool xok;
     uint32_t rowoff[NJ];
 #pragma unroll
@@ -151,23 +129,12 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
             xg[j] = *(const GLOBAL_AS V8*)(xb + off);
             if (ACT == 1) xu[j] = *(const GLOBAL_AS V8*)(xb + (int64_t)a.K * 2 + off);
         }
-        if (NORM) nw = ld16<V8>(reinterpret_cast<const T*>(a.norm_w) + kc);
     };
     auto stage_store = [&](int buf) {
         T* dst = xs + buf * (XR * DRS) + srow * DRS + scol;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             V8 t = xg[j];
-            if (NORM) {
-                float s2 = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float h = to_f32(t[e]);
-                    s2 += h * h;
-                    t[e] = from_f32<T>(h * to_f32(nw[e]));
-                }
-                if (xok) ssq[j] += s2;
-            }
             if (ACT == 1) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -205,7 +172,7 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
     // gptq_gemm_unit)
     unit_barrier();
 #pragma unroll
-    for (int s = 0; s < DR; ++s) w_load(s, wq[s]);
+    for (int s = 0; s < DRING; ++s) w_load(s, wq[s]);
     auto group_sync = [&](int target) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add((lds_int*)sync_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -224,7 +191,7 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
         for (int s4 = 0; s4 < 4; ++s4) {
             const int step = chunk * 4 + s4;
             const T* xk = xbuf + s4 * 64;
-            V8* cur = wq[s4 & (DR - 1)];
+            V8* cur = wq[s4 & (DRING - 1)];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -232,11 +199,11 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
                     V8 av = ld16<V8>(xk + mr * (32 * DRS) + i * 8);
                     accs[mr][i & 1] = mfma32(av, cur[i], accs[mr][i & 1]);
                 }
-            // the slot is consumed: refill it in place, DR steps ahead (the last chunk only refills what it
+            // the slot is consumed: refill it in place, DRING steps ahead (the last chunk only refills what it
             // will still consume itself)
-            if (!LAST || s4 + DR < 4) {
+            if (!LAST || s4 + DRING < 4) {
                 __builtin_amdgcn_sched_barrier(0);
-                w_load(step + DR, cur);
+                w_load(step + DRING, cur);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -261,30 +228,6 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
                 rcos[mr][j] = roth ? reinterpret_cast<const T*>(a.cosb)[(int64_t)rpos[mr][j] * (a.rD >> 1) + dr] : (T)1.f;
                 rsin[mr][j] = roth ? reinterpret_cast<const T*>(a.sinb)[(int64_t)rpos[mr][j] * (a.rD >> 1) + dr] : (T)0.f;
             }
-    }
-    // `res`: the residual elements this wave will add in the epilogue, asked for before the exchange as well
-    T resv[ACT == 0 ? MR : 1][ACT == 0 ? NR : 1];
-    if (ACT == 0 && a.res) {
-        const int ncl = min(nt * 32 + (lane & 31), a.N - 1);
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                const int r = wk * NR + j;
-                const int m = min(mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), mrows - 1);
-                resv[mr][j] = reinterpret_cast<const T*>(a.res)[(int64_t)(m0 + m) * a.ldo + ncl];
-            }
-    }
-    // NORM: the k-part's share of every row's sum(h^2) — the 32 threads of a half wave staged one row's pieces
-    float* ssq_lds = reinterpret_cast<float*>(smem + (size_t)WK * 2 * XR * DRS * sizeof(T) + 64);  // [WK][XR]
-    if (NORM) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            float v = ssq[j];
-#pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-            if ((lane & 31) == 0 && (NJ * RSTEP == XR || srow + RSTEP * j < XR)) ssq_lds[wk * XR + srow + RSTEP * j] = v;
-        }
     }
     unit_barrier();  // every k-part is done with its x buffers: the reduction below reuses them
 
@@ -327,19 +270,6 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
             const int r = wk * NR + j;
             return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         };
-        if (NORM) {
-            // rstd of the rows this wave finishes, from the k-parts' sums in fixed order; it scales the fp32 sum before the
-            // bias and the rounding, where the reference's normed activation would have carried it into the GEMM
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                for (int j = 0; j < NR; ++j) {
-                    float t = 0.f;
-#pragma unroll
-                    for (int k2 = 0; k2 < WK; ++k2) t += ssq_lds[k2 * XR + mr * 32 + row_of(j)];
-                    fin[mr][j] *= rsqrtf(t / (float)a.K + a.eps);
-                }
-        }
         if (ACT == 3) {
             // rope image: a tile of a q / k head holds dims [16 t, 16 t + 16) in lanes c < 16 and their rotation partners
             // rD/2 + [16 t, ..) in lanes c + 16; v heads keep 32 consecutive dims.  Sum (+ bias) rounded to T, rotated in
@@ -409,14 +339,10 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
                 for (int j = 0; j < NR; ++j) {
                     const int m = mr * 32 + row_of(j);
                     if (m >= mrows) continue;
-                    if (a.out_f32) {
+                    if (a.out_f32)
                         reinterpret_cast<float*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = fin[mr][j] + bv;
-                    } else {
-                        T o = finish_out<T>(fin[mr][j] + bv, a.gelu);
-                        if (ACT == 0 && a.res)  // the residual stream leaves this launch: T(T(out) + residual)
-                            o = from_f32<T>(to_f32(o) + to_f32(resv[mr][j]));
-                        reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = o;
-                    }
+                    else
+                        reinterpret_cast<T*>(a.out)[(int64_t)(m0 + m) * a.ldo + n] = finish_out<T>(fin[mr][j] + bv, a.gelu);
                 }
         } else {
 #pragma unroll
@@ -432,7 +358,6 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
 
 struct DensePlan {
     int KR, S, WK, TN, MR;
-    int DR = DRING;  // k64-steps of weights in flight per wave (4: the narrow unsplit grids of the folded layer)
 };
 
 // Plan with at most `max_units` units (one per CU).  `direct`: the output is finished in the epilogue (SiLU * up, rotary +

@@ -58,10 +58,10 @@ using dense::plan_dense;
 using dense::dense_slab_bytes;
 
 // One workgroup = one unit of dense_gemm_body.h (block-wide barriers, plain loads and stores).
-template <typename T, int TN, int WK, int ACT, int MR, bool NORM = false, int DR = dense::DRING>
+template <typename T, int TN, int WK, int ACT, int MR>
 __global__ __launch_bounds__(64 * TN * WK) void dense_gemm_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    dense::dense_gemm_unit<T, TN, WK, ACT, MR, NORM, DR>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    dense::dense_gemm_unit<T, TN, WK, ACT, MR>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 
@@ -93,18 +93,15 @@ __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float* _
 }
 
 
-// LDS of a unit: the x chunk buffers of its k-parts, the arrival counters, the k-parts' row sums of squares (NORM units)
-static size_t dense_lds_bytes(int WK, int MR, size_t elem) { return (size_t)WK * 2 * 32 * MR * DRS * elem + 64 + 4 * 64 * 4; }
-
-template <typename T, int TN, int WK, int ACT, int MR, bool NORM = false, int DR = dense::DRING>
+template <typename T, int TN, int WK, int ACT, int MR>
 static int launch_dense_one(dim3 grid, size_t lds, hipStream_t st, const DenseArgs& a) {
     static bool attr = false;
     if (!attr) {
-        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)dense_gemm_kernel<T, TN, WK, ACT, MR, NORM, DR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dense_lds_bytes(4, 1, 2)));
+        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)dense_gemm_kernel<T, TN, WK, ACT, MR>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * DRS * 2 + 64));
         attr = true;
     }
-    hipLaunchKernelGGL((dense_gemm_kernel<T, TN, WK, ACT, MR, NORM, DR>), grid, dim3(64 * TN * WK), lds, st, a);
+    hipLaunchKernelGGL((dense_gemm_kernel<T, TN, WK, ACT, MR>), grid, dim3(64 * TN * WK), lds, st, a);
     return TGIS_OK;
 }
 template <typename T, int TN, int WK, int ACT>
@@ -118,37 +115,8 @@ static int launch_dense_variant(int mr, dim3 grid, size_t lds, hipStream_t st, c
 template <typename T>
 static int launch_dense(const DenseArgs& a, const DensePlan& pl, int act, int64_t mslabs32, hipStream_t st) {
     dim3 grid((unsigned)cdiv64(a.NT, pl.TN), (unsigned)pl.S, (unsigned)cdiv64(mslabs32, pl.MR));
-    const size_t lds = dense_lds_bytes(pl.WK, pl.MR, sizeof(T));
+    const size_t lds = (size_t)pl.WK * 2 * 32 * pl.MR * DRS * sizeof(T) + 64;
     int rc = TGIS_EINVAL;
-    if (a.norm_w || pl.DR == 4) {
-        // The folded layer (round 6, tgis_dense_gemm_fold / tgis_dense_gemm_rope_fold): <= 32 rows, four k-parts, unsplit.
-        // NORM units for the consumers (SiLU * up, rotary + cache write, plain / fp32 logits), the four-step ring for the
-        // narrow grids of the producers (plain epilogue + residual).
-        const bool nrm = a.norm_w != nullptr;
-        const int key = pl.TN * 100 + act * 10 + (pl.DR == 4 ? 4 : 2);
-        if (pl.MR == 1 && pl.WK == 4 && pl.S == 1) {
-#define TGIS_FOLD_CASE(T_, A_, D_, N_)                                                        \
-    if (key == T_ * 100 + A_ * 10 + D_ && nrm == N_) rc = launch_dense_one<T, T_, 4, A_, 1, N_, D_>(grid, lds, st, a)
-            TGIS_FOLD_CASE(1, 3, 4, true);
-            TGIS_FOLD_CASE(2, 3, 2, true);
-            TGIS_FOLD_CASE(3, 3, 2, true);
-            TGIS_FOLD_CASE(1, 2, 4, true);
-            TGIS_FOLD_CASE(2, 2, 2, true);
-            TGIS_FOLD_CASE(3, 2, 2, true);
-            TGIS_FOLD_CASE(2, 0, 2, true);
-            TGIS_FOLD_CASE(3, 0, 2, true);
-            TGIS_FOLD_CASE(1, 0, 4, false);
-            TGIS_FOLD_CASE(2, 0, 4, false);
-#undef TGIS_FOLD_CASE
-        }
-        if (rc != TGIS_OK) {
-            tgis_set_error("tgis_dense_gemm_fold: no kernel for plan TN=%d WK=%d MR=%d S=%d DR=%d act=%d norm=%d", pl.TN, pl.WK,
-                           pl.MR, pl.S, pl.DR, act, (int)nrm);
-            return rc;
-        }
-        TGIS_CHECK_LAUNCH();
-        return TGIS_OK;
-    }
 #define TGIS_DENSE_CASE(T_, W_)                                                        \
     if (pl.TN == T_ && pl.WK == W_)                                                    \
         rc = act == 3   ? launch_dense_variant<T, T_, W_, 3>(pl.MR, grid, lds, st, a)                                           \
@@ -247,8 +215,6 @@ static void dense_fill(DenseArgs& a, const void* x, int64_t ldx, const void* pre
     a.slabs = slabs;
     a.partial = partial;
     a.gelu = 0;
-    a.norm_w = a.res = nullptr;
-    a.eps = 0.f;
     a.positions = a.slots = nullptr;
     a.cosb = a.sinb = nullptr;
     a.kpool = a.vpool = nullptr;
@@ -349,98 +315,4 @@ extern "C" int tgis_dense_gemm_partial(const void* x, int64_t ldx, const void* p
     dense_fill(a, x, ldx, prepared, nullptr, nullptr, 0, M, K, N, 0, slabs, 1, pl);
     return dtype == TGIS_F16 ? launch_dense<f16>(a, pl, act, cdiv64(M, 32), st)
                              : launch_dense<bf16>(a, pl, act, cdiv64(M, 32), st);
-}
-
-// ---- the folded layer (round 6): add + RMSNorm inside the GEMMs around it -------------------------------------------------
-// Unsplit plans only (the consumer needs every row's whole sum of squares, the producer its finished output): the SiLU / rope
-// plans for the consumers, the same k-parts-instead-of-splits plan for the producers, ONE tile per block where two would
-// leave fewer than 128 blocks (and then four k64-steps of weights in flight: 64 - 128 blocks do not saturate HBM, a block's
-// rate is its bytes in flight).
-static bool plan_dense_fold(int64_t K, int64_t N, int64_t M, int act, bool norm, DensePlan* out) {
-    if (M < 1 || M > 32 || K % 8 || K < 4 * dense::DKC || (act != 0 && act != 2 && act != 3)) return false;
-    const int64_t tiles = cdiv64(N, 32);
-    DensePlan pl = act == 3 ? plan_dense_rope(K, N, M) : (act == 0 && tiles >= 512) ? plan_dense(K, N, M, 0)
-                                                                                    : dense::plan_dense_tail(K, N, true, 256);
-    if (pl.S != 1 || pl.WK != 4 || pl.MR != 1) return false;
-    if (cdiv64(tiles, pl.TN) < 128) pl.TN = 1;
-    pl.DR = (pl.TN == 1 || !norm) ? 4 : dense::DRING;
-    // what launch_dense instantiates
-    // what launch_dense instantiates (four-tile NORM blocks — 1024 threads, 128 registers each — spill: not built)
-    const bool ok = norm ? (pl.TN == 1 ? act != 0 : pl.TN <= 3) : (act == 0 && pl.TN <= 2);
-    if (!ok) return false;
-    *out = pl;
-    return true;
-}
-
-extern "C" int tgis_dense_fold_ok(int64_t M, int64_t K, int64_t N, int act, int with_norm) {
-    DensePlan pl;
-    return plan_dense_fold(K, N, M, act, with_norm != 0, &pl) ? 1 : 0;
-}
-
-static int dense_fold_check(const tgis_fold* f, const char* who, bool epilogue_residual_allowed) {
-    TGIS_CHECK_ARG(f && (f->norm_weight || f->out_residual), "%s: the fold names neither a norm nor a residual", who);
-    TGIS_CHECK_ARG(!f->x_residual && !f->residual_out, "%s: x_residual (the consumer-side residual add of tensor-parallel ranks) "
-                   "exists for the int4 kernels only", who);
-    TGIS_CHECK_ARG(!f->out_residual || epilogue_residual_allowed, "%s: out_residual needs the plain model-dtype epilogue", who);
-    TGIS_CHECK_ARG(!f->norm_weight || f->eps > 0.f, "%s: eps must be positive", who);
-    return TGIS_OK;
-}
-
-extern "C" int tgis_dense_gemm_fold(const void* x, int64_t ldx, const void* prepared, const void* bias, void* out, int64_t ldo,
-                                    int64_t M, int64_t K, int64_t N, int dtype, int out_f32, int act, const tgis_fold* fold,
-                                    void* stream) {
-    int rc = dense_check(x, ldx, prepared, M, K, N, dtype, act);
-    if (rc != TGIS_OK) return rc;
-    TGIS_CHECK_ARG(out && (act == 0 || act == 2), "tgis_dense_gemm_fold: act 0 (plain) or 2 (SiLU * up image)");
-    rc = dense_fold_check(fold, "tgis_dense_gemm_fold", act == 0 && !out_f32);
-    if (rc != TGIS_OK) return rc;
-    TGIS_CHECK_ARG(!(fold->norm_weight && fold->out_residual), "tgis_dense_gemm_fold: a launch is a consumer (norm_weight) or a "
-                   "producer (out_residual) of the residual stream, not both");
-    TGIS_CHECK_ARG(act != 2 || !out_f32, "tgis_dense_gemm_fold: act 2 writes the model dtype");
-    DensePlan pl;
-    TGIS_CHECK_ARG(plan_dense_fold(K, N, M, act, fold->norm_weight != nullptr, &pl),
-                   "tgis_dense_gemm_fold: no folded launch for M=%ld K=%ld N=%ld act=%d (ask tgis_dense_fold_ok)", (long)M,
-                   (long)K, (long)N, act);
-    hipStream_t st = (hipStream_t)stream;
-    TgisTimedScope timed(TGIS_OP_DENSE_GEMM, st);
-    DenseArgs a;
-    dense_fill(a, x, ldx, prepared, bias, out, ldo, M, K, N, out_f32, nullptr, 0, pl);
-    a.norm_w = fold->norm_weight;
-    a.eps = fold->eps;
-    a.res = fold->out_residual;
-    return dtype == TGIS_F16 ? launch_dense<f16>(a, pl, act, 1, st) : launch_dense<bf16>(a, pl, act, 1, st);
-}
-
-extern "C" int tgis_dense_gemm_rope_fold(const void* x, int64_t ldx, const void* prepared, const void* bias,
-                                         const int32_t* positions, const int32_t* slots, const void* cos, const void* sin,
-                                         void* q_out, int64_t ldq, void* k_pool, void* v_pool, int64_t M, int64_t K, int64_t N,
-                                         int64_t H, int64_t Hkv, int64_t D, int dtype, const tgis_fold* fold, void* stream) {
-    int rc = dense_check(x, ldx, prepared, M, K, N, dtype, 0);
-    if (rc != TGIS_OK) return rc;
-    TGIS_CHECK_ARG(positions && slots && cos && sin && q_out && k_pool && v_pool, "tgis_dense_gemm_rope_fold: null tensor");
-    TGIS_CHECK_ARG(D >= 32 && D % 32 == 0 && H >= 1 && Hkv >= 1 && (H + 2 * Hkv) * D == N && ldq >= H * D,
-                   "tgis_dense_gemm_rope_fold: N must be (H + 2 Hkv) * D, D a multiple of 32, q rows of H * D elements");
-    rc = dense_fold_check(fold, "tgis_dense_gemm_rope_fold", false);
-    if (rc != TGIS_OK) return rc;
-    TGIS_CHECK_ARG(fold->norm_weight, "tgis_dense_gemm_rope_fold: needs norm_weight (without it: tgis_dense_gemm_rope)");
-    DensePlan pl;
-    TGIS_CHECK_ARG(plan_dense_fold(K, N, M, 3, true, &pl),
-                   "tgis_dense_gemm_rope_fold: no folded launch for M=%ld K=%ld N=%ld (ask tgis_dense_fold_ok)", (long)M, (long)K,
-                   (long)N);
-    hipStream_t st = (hipStream_t)stream;
-    TgisTimedScope timed(TGIS_OP_DENSE_GEMM, st);
-    DenseArgs a;
-    dense_fill(a, x, ldx, prepared, bias, q_out, ldq, M, K, N, 0, nullptr, 0, pl);
-    a.positions = positions;
-    a.slots = slots;
-    a.cosb = cos;
-    a.sinb = sin;
-    a.kpool = k_pool;
-    a.vpool = v_pool;
-    a.rH = (int)H;
-    a.rHkv = (int)Hkv;
-    a.rD = (int)D;
-    a.norm_w = fold->norm_weight;
-    a.eps = fold->eps;
-    return dtype == TGIS_F16 ? launch_dense<f16>(a, pl, 3, 1, st) : launch_dense<bf16>(a, pl, 3, 1, st);
 }

@@ -78,14 +78,6 @@ class KVArgs:
 # measured slower than the launches they replace: experiments/README.md is their ledger.)
 
 
-# Decode steps of up to 32 rows on dense (f16 / bf16) weights, one GPU: the two add + RMSNorm launches of a layer are folded
-# into the GEMMs around them (native.dense_gemm_fold / dense_gemm_rope_fold, tgis_fold in include/tgis_hip.h) — o_proj and
-# down_proj add the residual in their epilogue and write the residual stream, qkv and gate_up normalise it while they stage
-# it: five launches per layer instead of seven (TinyLlama, B = 16: 1.06 -> see DESIGN.md section 6 round 6).  "false" keeps
-# the seven launches (A/B, and the bit-exact reference chain the fold is tested against).
-FOLD_NORM = os.getenv("TGIS_FOLD_NORM", "true").lower() not in ("0", "false")
-
-
 def frag_rows(linear, rows: int, kv: "KVArgs", act: int = 0) -> bool:
     """Decode step of <= 64 rows in front of an int4 linear that takes its operand in fragment order (native.FragAct)."""
     return (kv.max_q_len == 1 and not kv.fresh_prefill and rows <= 64 and hasattr(linear, "wants_fragments")
@@ -235,49 +227,10 @@ class FlashLlamaLayer:
                                             eps=config.rms_norm_eps)
         self.post_attention_layernorm = LlamaRMSNorm(prefix=f"{prefix}.post_attention_layernorm", weights=weights,
                                                      eps=config.rms_norm_eps)
-        self._folds = {}  # rows -> bool (see `folds`)
-
-    def folds(self, rows: int, cos, kv: KVArgs) -> bool:
-        """Does this layer run as five launches (the norms folded into the GEMMs) for a decode step of `rows` rows?"""
-        got = self._folds.get(rows)
-        if got is None:
-            from tgis_amd.utils.layers import FastLinear
-
-            att, mlp = self.self_attn, self.mlp
-            lins = (att.query_key_value.linear, att.o_proj.linear, mlp.gate_up_proj.linear, mlp.down_proj.linear)
-            got = (FOLD_NORM and rows <= 32 and all(isinstance(l, FastLinear) for l in lins)
-                   and att.o_proj.process_group.size() == 1 and mlp.fused_epilogue
-                   and lins[0].rope_handle is not None and cos.shape[1] * 2 == att.head_size
-                   and native.dense_fold_ok(rows, lins[0].rope_handle, 3, True)
-                   and native.dense_fold_ok(rows, lins[1].prepared, 0, False)
-                   and native.dense_fold_ok(rows, lins[2].prepared, 2, True)
-                   and native.dense_fold_ok(rows, lins[3].prepared, 0, False))
-            self._folds[rows] = got
-        return got and kv.max_q_len == 1 and not kv.fresh_prefill and kv.slots is not None
-
-    def forward_folded(self, h, cos, sin, position_ids, cu_seqlens_q, kv: KVArgs):
-        """The layer on the residual stream `h` (= the reference's hidden_states + residual, rounded): returns the next one.
-        Same five GEMM / attention launches as `forward`, without its two add + RMSNorm launches."""
-        att, mlp = self.self_attn, self.mlp
-        ln1, ln2 = self.input_layernorm, self.post_attention_layernorm
-        qkv_lin = att.query_key_value.linear
-        k_pool, v_pool = kv.cache.k_pool(self.layer_id), kv.cache.v_pool(self.layer_id)
-        qkv = native.dense_gemm_rope_fold(h, qkv_lin.rope_handle, qkv_lin.bias, cos, sin, position_ids, kv.slots, k_pool, v_pool,
-                                          att.num_heads, att.num_key_value_heads, att.head_size, ln1.weight,
-                                          ln1.variance_epsilon)
-        attn_output = att.attend(qkv, cu_seqlens_q, self.layer_id, kv)
-        o = att.o_proj.linear
-        h = native.dense_gemm_fold(attn_output, o.prepared, bias=o.bias, out_residual=h)
-        gu, down = mlp.gate_up_proj.linear, mlp.down_proj.linear
-        act = native.dense_gemm_fold(h, gu.prepared, bias=gu.bias, act=2, norm_weight=ln2.weight, eps=ln2.variance_epsilon)
-        return native.dense_gemm_fold(act, down.prepared, bias=down.bias, out_residual=h)
 
     def forward(self, hidden_states, residual, cos, sin, position_ids, cu_seqlens_q, kv: KVArgs):
         rows = hidden_states.shape[0]
         att = self.self_attn
-        if residual is None and self.folds(rows, cos, kv):
-            # (the stream needs no residual partner: the next layer, or the final norm, gets residual = None)
-            return self.forward_folded(hidden_states, cos, sin, position_ids, cu_seqlens_q, kv), None
         # decode steps of <= 32 rows hand the int4 GEMMs their operands in fragment order (native.FragAct): the qkv + rotary
         # launch when it serves the step, the MLP when the SiLU * up epilogue does
         qkv_frag = (kv.slots is not None and cos.shape[1] * 2 == att.head_size

@@ -27,11 +27,6 @@ _vp = ctypes.c_void_p
 
 
 
-class Fold(ctypes.Structure):
-    """tgis_fold (include/tgis_hip.h): the add + RMSNorm around a decode GEMM folded into it."""
-    _fields_ = [("norm_weight", _vp), ("eps", _c_f), ("x_residual", _vp), ("residual_out", _vp), ("out_residual", _vp)]
-
-
 # name -> (restype, argtypes); must list every symbol declared in include/tgis_hip.h
 SIGNATURES = {
     "tgis_version": (ctypes.c_char_p, []),
@@ -64,11 +59,6 @@ SIGNATURES = {
     "tgis_dense_gemm_workspace_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
     "tgis_dense_gemm": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int,
                                  _c_int, _vp, _c_i64, _vp]),
-    "tgis_dense_fold_ok": (_c_int, [_c_i64, _c_i64, _c_i64, _c_int, _c_int]),
-    "tgis_dense_gemm_fold": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int,
-                                      ctypes.POINTER(Fold), _vp]),
-    "tgis_dense_gemm_rope_fold": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _c_i64,
-                                           _c_i64, _c_i64, _c_i64, _c_i64, _c_int, ctypes.POINTER(Fold), _vp]),
     "tgis_dense_gemm_partial_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64]),
     "tgis_dense_gemm_partial": (_c_int, [_vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _vp, _c_i64,
                                          ctypes.POINTER(_c_int), ctypes.POINTER(_c_i64), _vp]),
@@ -524,64 +514,6 @@ def dense_gemm_rope(x: torch.Tensor, w: DenseWeight, bias, cos, sin, positions, 
                                             _ptr(cos), _ptr(sin), _ptr(out), out.stride(0), _ptr(k_pool), _ptr(v_pool), M,
                                             w.K, w.N, H, Hkv, D, dtype_code(w.dtype), _stream()),
         "tgis_dense_gemm_rope")
-    return out
-
-
-# ---- the folded layer (round 6): add + RMSNorm inside the GEMMs around it ---------------------------------------------------
-def dense_fold_ok(M: int, w: DenseWeight, act: int, with_norm: bool) -> bool:
-    """Does the folded launch exist for M rows of this weight (tgis_dense_fold_ok)?  act 0 plain, 2 SiLU * up image, 3 rope
-    image; with_norm: the consumer form (RMSNorm folded into the operand staging) / the producer form (residual epilogue)."""
-    key = ("fold_ok", M, act, bool(with_norm))
-    cache = w.__dict__.setdefault("_fold_ok", {})
-    got = cache.get(key)
-    if got is None:
-        got = cache[key] = bool(load_library().tgis_dense_fold_ok(M, w.K, w.N, act, int(bool(with_norm))))
-    return got
-
-
-def _fold(norm_weight=None, eps: float = 0.0, out_residual=None) -> Fold:
-    return Fold(_ptr(norm_weight), float(eps), None, None, _ptr(out_residual))
-
-
-def dense_gemm_fold(x: torch.Tensor, w: DenseWeight, bias=None, act: int = 0, norm_weight=None, eps: float = 0.0,
-                    out_residual=None, out=None) -> torch.Tensor:
-    """A decode GEMM (<= 32 rows) with half of the reference's fused add + RMSNorm inside it (tgis_dense_gemm_fold).
-    norm_weight: `x` is the residual stream h and the operand is RMSNorm(h) — act 0 or 2 (SiLU * up image);
-    out_residual [M, N]: the result is T(T(x @ W^T + bias) + out_residual), the new residual stream (act 0)."""
-    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == w.dtype and x.shape[1] == w.K
-    assert (act == 2) == bool(w.flags & 1), "act 2 runs on (and only on) a gate|up image"
-    assert (norm_weight is None) != (out_residual is None), "consumer (norm_weight) or producer (out_residual)"
-    M = x.shape[0]
-    if out is None:
-        out = torch.empty((M, w.N // 2 if act == 2 else w.N), dtype=w.dtype, device=x.device)
-    if out_residual is not None:
-        assert out_residual.shape == out.shape and out_residual.stride() == out.stride() and out_residual.dtype == w.dtype
-    if norm_weight is not None:
-        assert norm_weight.dtype == w.dtype and norm_weight.numel() == w.K and norm_weight.is_contiguous()
-    f = _fold(norm_weight, eps, out_residual)
-    _check(
-        load_library().tgis_dense_gemm_fold(_ptr(x), x.stride(0), _ptr(w.image), _ptr(bias), _ptr(out), out.stride(0), M, w.K,
-                                            w.N, dtype_code(w.dtype), 0, act, ctypes.byref(f), _stream()),
-        "tgis_dense_gemm_fold")
-    return out
-
-
-def dense_gemm_rope_fold(x: torch.Tensor, w: DenseWeight, bias, cos, sin, positions, slots, k_pool, v_pool, H: int, Hkv: int,
-                         D: int, norm_weight, eps: float, out=None) -> torch.Tensor:
-    """dense_gemm_rope on the residual stream: RMSNorm(x) is formed while the operand is staged (tgis_dense_gemm_rope_fold)."""
-    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == w.dtype and x.shape[1] == w.K
-    assert w.flags & 2 and w.N == (H + 2 * Hkv) * D and cos.dtype == w.dtype and cos.shape[1] * 2 == D
-    assert positions.dtype == torch.int32 and slots.dtype == torch.int32
-    assert norm_weight.dtype == w.dtype and norm_weight.numel() == w.K and norm_weight.is_contiguous()
-    M = x.shape[0]
-    if out is None:
-        out = torch.empty((M, w.N), dtype=w.dtype, device=x.device)
-    f = _fold(norm_weight, eps)
-    _check(
-        load_library().tgis_dense_gemm_rope_fold(_ptr(x), x.stride(0), _ptr(w.image), _ptr(bias), _ptr(positions), _ptr(slots),
-                                                 _ptr(cos), _ptr(sin), _ptr(out), out.stride(0), _ptr(k_pool), _ptr(v_pool), M,
-                                                 w.K, w.N, H, Hkv, D, dtype_code(w.dtype), ctypes.byref(f), _stream()),
-        "tgis_dense_gemm_rope_fold")
     return out
 
 
