@@ -90,7 +90,10 @@ def test_gptq_gemm_fused_silu(nat, gpu_device):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,K,N,f32out", [(32, 4096, 32000, True), (16, 2048, 2560, False), (3, 200, 72, False),
                                           (64, 2048, 5632, False), (100, 1024, 160, True),
-                                         (40, 512, 100, True)])
+                                         (40, 512, 100, True),
+                                         # batches of up to 16 rows stage 16 rows of x (round 6, R16) — every plan family
+                                         (16, 5632, 2048, False), (9, 2048, 32000, True), (1, 2048, 2048, False),
+                                         (13, 6144, 6400, False), (16, 24576, 6144, False), (17, 2048, 2048, False)])
 def test_dense_gemm(nat, gpu_device, dtype, M, K, N, f32out):
     g = torch.Generator().manual_seed(M + K + N)
     x = (torch.randn(M, K, generator=g) * 0.5).to(dtype)

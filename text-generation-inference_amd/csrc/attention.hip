@@ -78,6 +78,12 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     const int hk = by / a.HCB, hc0 = (by % a.HCB) * CH;  // first 16-head chunk of this block
     const int b = bz / a.NS, split = bz % a.NS;
 
+    // Unsplit launches (NS == 1: every block starts at page 0): this wave's first block-table entry does not depend on the
+    // sequence's length, so it is requested together with the lengths instead of behind them — one dependent scalar round trip
+    // less in front of the first K / V load (inside a decode step those lines are not in this XCD's L2: the GEMMs of the layer
+    // have streamed ~100 MB through it since the last attention launch; profiles/r06_attn_cold.log).
+    const int32_t* btrow = a.bt + (int64_t)b * a.max_pages;
+    const int pg_spec = (a.NS == 1 && w < a.max_pages) ? btrow[w] : 0;
     const int q0 = a.cu_q[b], q_len = a.cu_q[b + 1] - q0;
     const int t0 = qt * a.TQ;
     if (t0 >= q_len) return;
@@ -98,8 +104,7 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     // The first fully visible page's table entry is asked for HERE — as soon as the lengths are in, in front of the q loads and
     // of the partly visible pages: behind them it was a scalar round trip with nothing of this wave in flight (round 5 timeline,
     // profiles/r05_attn_timeline.log: multi-chunk blocks had their first entry 4.8 k ticks after entry, 3.5 k after the lengths).
-    const int32_t* btrow = a.bt + (int64_t)b * a.max_pages;
-    const int pg_first = (pbeg + w < pend) ? btrow[pbeg + w] : 0;
+    const int pg_first = a.NS == 1 ? pg_spec : ((pbeg + w < pend) ? btrow[pbeg + w] : 0);
 
     // Q^T fragments (B operand): lane supplies Q[col][ks*32 + c*8 .. +8]
     V8 qf[CH][KS];
@@ -459,22 +464,49 @@ __global__ __launch_bounds__(64 * NW) void attn_paged_kernel(AttnArgs a) {
     }
 }
 
-// out[tok][head][:] = sum_s O_s * 2^(m_s - m*) / sum_s l_s * 2^(m_s - m*);  one wave per (tok, head)
-template <typename T, int D>
-__global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restrict__ ws_o,
-                                                          const float* __restrict__ ws_ml, T* __restrict__ out,
-                                                          int NS, int H, int out_frag) {
-    const int64_t th = blockIdx.x;  // tok*H + head
-    const int lane = threadIdx.x;
+// out[tok][head][:] = sum_s O_s * 2^(m_s - m*) / sum_s l_s * 2^(m_s - m*);  one wave per (tok, head), four per workgroup.
+// MAXS > 0 (NS <= MAXS): every record of the row — {m, l} and the O slice of each split — is requested before the first use,
+// so the launch is ONE round trip to the records instead of two dependent passes over them (round 6: the MQA launch pair
+// spends 4.5 of its 26 us here); MAXS == 0: any NS, the two-pass loop.  Same expressions in the same order either way.
+template <typename T, int D, int MAXS>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ ws_o,
+                                                           const float* __restrict__ ws_ml, T* __restrict__ out,
+                                                           int NS, int H, int out_frag, int64_t rows) {
+    const int64_t th = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // tok*H + head
+    if (th >= rows) return;
+    const int lane = threadIdx.x & 63;
     float mstar = NEG_BIG;
-    for (int s = 0; s < NS; ++s) mstar = fmaxf(mstar, ws_ml[(th * NS + s) * 2]);
     float l = 0.f;
     float acc[D / 64] = {};
-    for (int s = 0; s < NS; ++s) {
-        float f = exp2f(ws_ml[(th * NS + s) * 2] - mstar);
-        l += ws_ml[(th * NS + s) * 2 + 1] * f;
+    if (MAXS > 0) {
+        float ms[MAXS ? MAXS : 1], ls[MAXS ? MAXS : 1], os[MAXS ? MAXS : 1][D / 64];
 #pragma unroll
-        for (int i = 0; i < D / 64; ++i) acc[i] += ws_o[(th * NS + s) * D + i * 64 + lane] * f;
+        for (int s = 0; s < MAXS; ++s) {
+            const int64_t r = th * NS + min(s, NS - 1);
+            ms[s] = ws_ml[r * 2];
+            ls[s] = ws_ml[r * 2 + 1];
+#pragma unroll
+            for (int i = 0; i < D / 64; ++i) os[s][i] = ws_o[r * D + i * 64 + lane];
+        }
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+            if (s < NS) mstar = fmaxf(mstar, ms[s]);
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+            if (s < NS) {
+                const float f = exp2f(ms[s] - mstar);
+                l += ls[s] * f;
+#pragma unroll
+                for (int i = 0; i < D / 64; ++i) acc[i] += os[s][i] * f;
+            }
+    } else {
+        for (int s = 0; s < NS; ++s) mstar = fmaxf(mstar, ws_ml[(th * NS + s) * 2]);
+        for (int s = 0; s < NS; ++s) {
+            float f = exp2f(ws_ml[(th * NS + s) * 2] - mstar);
+            l += ws_ml[(th * NS + s) * 2 + 1] * f;
+#pragma unroll
+            for (int i = 0; i < D / 64; ++i) acc[i] += ws_o[(th * NS + s) * D + i * 64 + lane] * f;
+        }
     }
     const float inv = l > 0.f ? 1.f / l : 0.f;
 #pragma unroll
@@ -564,8 +596,13 @@ static int launch_attn(const AttnArgs& a, dim3 grid, int64_t total_q, hipStream_
         launch_attn_nw<T, D, 1>(a, grid, st, nw);
     TGIS_CHECK_LAUNCH();
     if (a.NS > 1 && !a.counters) {
-        hipLaunchKernelGGL((attn_combine_kernel<T, D>), dim3((unsigned)(total_q * a.H)), dim3(64), 0, st, a.ws_o,
-                           a.ws_ml, (T*)a.out, a.NS, a.H, a.out_frag);
+        const int64_t rows = total_q * a.H;
+        if (a.NS <= 8)
+            hipLaunchKernelGGL((attn_combine_kernel<T, D, 8>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, st, a.ws_o,
+                               a.ws_ml, (T*)a.out, a.NS, a.H, a.out_frag, rows);
+        else
+            hipLaunchKernelGGL((attn_combine_kernel<T, D, 0>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, st, a.ws_o,
+                               a.ws_ml, (T*)a.out, a.NS, a.H, a.out_frag, rows);
         TGIS_CHECK_LAUNCH();
     }
     return TGIS_OK;

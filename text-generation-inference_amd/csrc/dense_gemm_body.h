@@ -59,13 +59,19 @@ __device__ __forceinline__ T finish_out(float v, int gelu) {
 //   out[m][j] = T(T(silu(T gate)) * T up), [rows, N/2] — once per element, where ACT = 1 recomputes the SiLU in every
 //   column block of the consumer.  Needs S == 1 (the planner guarantees it).
 // MR = 32-row blocks of x per pass (2 for M > 32: every weight fragment then feeds two MFMAs; needs WK = 2).
-template <typename T, int TN, int WK, int ACT, int MR>
+// R16 (batches of up to 16 rows, MR == 1): only 16 rows of x are staged — half the requests through the CU's address path,
+// half the LDS stores and half the LDS footprint per chunk; lanes 16 - 31 of the A fragment re-read rows 0 - 15 (an LDS
+// broadcast), so accumulator rows 16 - 31 repeat rows 0 - 15 and are never stored.  Round 6: at TinyLlama's widths the
+// activation is a third to a half of what a block takes in, and rows 16 - 31 of a 16-sequence batch were clamped copies.
+template <typename T, int TN, int WK, int ACT, int MR, bool R16 = false>
 __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int ntg, const int split, const int mslab,
                                                 unsigned char* smem) {
     static_assert(MR == 1 || WK == 2, "64-row passes need the LDS of two k-parts");
     static_assert(WK > 1, "the finish below exchanges k-parts");
     using V8 = typename VecT<T>::x8;
-    constexpr int XR = 32 * MR;
+    static_assert(!R16 || MR == 1, "16-row staging is for single 32-row passes");
+    constexpr int SLAB = 32 * MR;          // rows of the output this pass owns
+    constexpr int XR = R16 ? 16 : SLAB;    // rows of x staged per chunk
     constexpr int GT = 64 * TN;
     constexpr int NJ = (XR * 32 + GT - 1) / GT;
     constexpr int RSTEP = GT / 32;
@@ -73,8 +79,8 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = w % TN, wk = w / TN, ltid = wn * 64 + lane;
     T* xs = reinterpret_cast<T*>(smem) + wk * (2 * XR * DRS);
-    const int m0 = mslab * XR;
-    const int mrows = min(XR, a.M - m0);
+    const int m0 = mslab * SLAB;
+    const int mrows = min(XR, a.M - m0);   // (R16: the host guarantees M <= 16)
     const int krp = a.KR / WK;
     const int k0 = split * a.KR + wk * krp;
     const int k1 = min(a.K, k0 + krp);
@@ -157,7 +163,7 @@ __device__ __forceinline__ void dense_gemm_unit(const DenseArgs& a, const int nt
     for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
         for (int i = 0; i < 2; ++i) accs[mr][i] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int xoff = (lane & 31) * DRS + (lane >> 5) * 32;
+    const int xoff = (lane & (R16 ? 15 : 31)) * DRS + (lane >> 5) * 32;
 
     volatile lds_int* sync_cnt = (volatile lds_int*)(smem + (size_t)WK * 2 * XR * DRS * sizeof(T)) + wk;
     // all waves of the unit meet here; the LDS traffic a wave issued before is complete when it arrives

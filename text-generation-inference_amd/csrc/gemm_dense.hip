@@ -58,10 +58,10 @@ using dense::plan_dense;
 using dense::dense_slab_bytes;
 
 // One workgroup = one unit of dense_gemm_body.h (block-wide barriers, plain loads and stores).
-template <typename T, int TN, int WK, int ACT, int MR>
+template <typename T, int TN, int WK, int ACT, int MR, bool R16 = false>
 __global__ __launch_bounds__(64 * TN * WK) void dense_gemm_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    dense::dense_gemm_unit<T, TN, WK, ACT, MR>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    dense::dense_gemm_unit<T, TN, WK, ACT, MR, R16>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 
@@ -93,22 +93,29 @@ __global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(const float* _
 }
 
 
-template <typename T, int TN, int WK, int ACT, int MR>
+template <typename T, int TN, int WK, int ACT, int MR, bool R16 = false>
 static int launch_dense_one(dim3 grid, size_t lds, hipStream_t st, const DenseArgs& a) {
     static bool attr = false;
     if (!attr) {
-        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)dense_gemm_kernel<T, TN, WK, ACT, MR>,
+        TGIS_CHECK_HIP(hipFuncSetAttribute((const void*)dense_gemm_kernel<T, TN, WK, ACT, MR, R16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * DRS * 2 + 64));
         attr = true;
     }
-    hipLaunchKernelGGL((dense_gemm_kernel<T, TN, WK, ACT, MR>), grid, dim3(64 * TN * WK), lds, st, a);
+    hipLaunchKernelGGL((dense_gemm_kernel<T, TN, WK, ACT, MR, R16>), grid, dim3(64 * TN * WK), lds, st, a);
     return TGIS_OK;
+}
+static bool rows16_enabled() {  // A/B hook: TGIS_DENSE_ROWS16=0 stages 32 rows whatever the batch
+    static const bool on = !(getenv("TGIS_DENSE_ROWS16") && atoi(getenv("TGIS_DENSE_ROWS16")) == 0);
+    return on;
 }
 template <typename T, int TN, int WK, int ACT>
 static int launch_dense_variant(int mr, dim3 grid, size_t lds, hipStream_t st, const DenseArgs& a) {
     if constexpr (WK == 2) {
         if (mr == 2) return launch_dense_one<T, TN, WK, ACT, 2>(grid, lds, st, a);
     }
+    // batches of up to 16 rows stage 16 rows of x (dense_gemm_body.h, R16); the LDS request shrinks with them
+    if (a.M <= 16 && rows16_enabled())
+        return launch_dense_one<T, TN, WK, ACT, 1, true>(grid, (size_t)WK * 2 * 16 * DRS * sizeof(T) + 64, st, a);
     return launch_dense_one<T, TN, WK, ACT, 1>(grid, lds, st, a);
 }
 
