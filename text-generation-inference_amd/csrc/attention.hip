@@ -597,7 +597,8 @@ static int launch_attn(const AttnArgs& a, dim3 grid, int64_t total_q, hipStream_
     TGIS_CHECK_LAUNCH();
     if (a.NS > 1 && !a.counters) {
         const int64_t rows = total_q * a.H;
-        if (a.NS <= 8)
+        static const bool one_trip = !(getenv("TGIS_ATTN_COMBINE") && atoi(getenv("TGIS_ATTN_COMBINE")) == 0);  // A/B hook
+        if (a.NS <= 8 && one_trip)
             hipLaunchKernelGGL((attn_combine_kernel<T, D, 8>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, st, a.ws_o,
                                a.ws_ml, (T*)a.out, a.NS, a.H, a.out_frag, rows);
         else
@@ -638,7 +639,9 @@ extern "C" int tgis_attn_num_splits(int64_t B, int Hkv, int H, int64_t max_q_len
         // not in the launch (a last-arriving block reads NS x 24 KB through ONE CU: 2.7 us at 4 splits, 5.4 at 8).
         // 48 q heads on 1 kv head, B=32 ctx 4096, us (kernel + combine): 26.7 at 4 splits, 25.1 at 6, 25.3 at 8
         // (in-launch merge: 28.1 / 28.6 / 30.2)
-        ns = std::min<int64_t>(cdiv64(192, base), pages / 16);
+        // round 6: with the combine launch down to one round trip (24.1 vs 25.3 us at 6 splits) 8 splits = 256 blocks edge out
+        // 6 (23.9 vs 24.2, profiles/r06_mqa_variants.log)
+        ns = std::min<int64_t>(cdiv64(256, base), pages / 16);
     } else {
         ns = cdiv64(512, base);
         ns = std::min<int64_t>(ns, cdiv64(pages, 4));  // at least one page per wave
