@@ -70,7 +70,7 @@ int tgis_timing_read(int op, int64_t* count, double* total_ms);
 /* Bytes of the prepared (repacked) weight image for a [K,N] 4-bit matrix with `groups` groups. */
 int64_t tgis_gptq_prepared_bytes(int64_t K, int64_t N, int64_t groups);
 
-/* Repack GPTQ tensors into the kernel layout (DESIGN.md §4.1).  One-time, at load
+/* Repack GPTQ tensors into the kernel layout (DESIGN.md §3).  One-time, at load
  * (the reference does this in Ex4bitLinearV2.post_init, exllamav2.py:124-137).
  *   qweight [K/8, N] int32, qzeros [groups, N/8] int32, scales [groups, N] f16,
  *   g_idx [K] int32 or NULL (NULL = trivial k / groupsize), perm_out [K] int32 or NULL:

@@ -597,8 +597,7 @@ static int launch_attn(const AttnArgs& a, dim3 grid, int64_t total_q, hipStream_
     TGIS_CHECK_LAUNCH();
     if (a.NS > 1 && !a.counters) {
         const int64_t rows = total_q * a.H;
-        static const bool one_trip = !(getenv("TGIS_ATTN_COMBINE") && atoi(getenv("TGIS_ATTN_COMBINE")) == 0);  // A/B hook
-        if (a.NS <= 8 && one_trip)
+        if (a.NS <= 8)
             hipLaunchKernelGGL((attn_combine_kernel<T, D, 8>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, st, a.ws_o,
                                a.ws_ml, (T*)a.out, a.NS, a.H, a.out_frag, rows);
         else

@@ -104,17 +104,14 @@ static int launch_dense_one(dim3 grid, size_t lds, hipStream_t st, const DenseAr
     hipLaunchKernelGGL((dense_gemm_kernel<T, TN, WK, ACT, MR, R16>), grid, dim3(64 * TN * WK), lds, st, a);
     return TGIS_OK;
 }
-static bool rows16_enabled() {  // A/B hook: TGIS_DENSE_ROWS16=0 stages 32 rows whatever the batch
-    static const bool on = !(getenv("TGIS_DENSE_ROWS16") && atoi(getenv("TGIS_DENSE_ROWS16")) == 0);
-    return on;
-}
 template <typename T, int TN, int WK, int ACT>
 static int launch_dense_variant(int mr, dim3 grid, size_t lds, hipStream_t st, const DenseArgs& a) {
     if constexpr (WK == 2) {
         if (mr == 2) return launch_dense_one<T, TN, WK, ACT, 2>(grid, lds, st, a);
     }
-    // batches of up to 16 rows stage 16 rows of x (dense_gemm_body.h, R16); the LDS request shrinks with them
-    if (a.M <= 16 && rows16_enabled())
+    // batches of up to 16 rows stage 16 rows of x (dense_gemm_body.h, R16); the LDS request shrinks with them.  Same box,
+    // 32-row staging patched back in: cfg2 1.066 / 1.067 -> 1.038 / 1.044 ms per step (profiles/r06d_bench_cfg2_rows16_*.json)
+    if (a.M <= 16)
         return launch_dense_one<T, TN, WK, ACT, 1, true>(grid, (size_t)WK * 2 * 16 * DRS * sizeof(T) + 64, st, a);
     return launch_dense_one<T, TN, WK, ACT, 1>(grid, lds, st, a);
 }

@@ -5,7 +5,7 @@
 // utils/gptq/exllamav2.py:14-62,124-144.  Normative arithmetic (utils/gptq/quant_linear.py:130-138,
 // 184-194):  W[k,n] = (q[k,n] - (z[g(k),n] + 1)) * s[g(k),n];  y = x @ W, fp32 accumulate, f16 out.
 //
-// Prepared image (DESIGN.md §4.1), NT = ceil(N/32) column tiles, KS = ceil(K/64) k-steps, G groups:
+// Prepared image (DESIGN.md §3), NT = ceil(N/32) column tiles, KS = ceil(K/64) k-steps, G groups:
 //   A: wq [NT][KS][64 lanes][4] int32 — lane l word i = the 8 nibbles of rows
 //        k = (ks*8 + (l>>5)*4 + i)*8 + {0,2,4,6,1,3,5,7} of column n = nt*32 + (l&31): one KiB per wave
 //        load, and (after dequant8) exactly the B-operand fragment of v_mfma_f32_32x32x16_f16

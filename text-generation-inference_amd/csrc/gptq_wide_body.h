@@ -60,7 +60,6 @@ static inline WidePlan plan_wide(int64_t K, int64_t N, int act, int64_t M = 32, 
         if (sscanf(ov, "%d,%d", &ct, &sp) == 2 && ct >= 1 && ct <= 4 && sp >= 1 && (sp == 1 || (act != 2 && act != 3)))
             return {ct, sp};
     }
-    static const bool ct1 = !(getenv("TGIS_GPTQ_WIDE_CT1") && atoi(getenv("TGIS_GPTQ_WIDE_CT1")) == 0);  // A/B hook
     const int64_t tiles = cdiv64(N, 32), steps = K / 64;
     int CT = 2;
     while (CT < 4 && cdiv64(tiles, CT) > 256) ++CT;
@@ -68,7 +67,7 @@ static inline WidePlan plan_wide(int64_t K, int64_t N, int act, int64_t M = 32, 
     // (SiLU * up of a 64-row shard with a long k range — 70B gate_up at TP = 8, 224 one-tile blocks that each take in a 1 MiB
     // activation, 20.3 us for 29 MB — was also run split over k with the activation in the reduce launch, CT x S = 1x2, 2x2,
     // 4x4, 4x2, 2x4: none beat the unsplit plan on the rank step, profiles/r05_tp8_silu_plans.log.)
-    if (ct1 && tiles <= 256 && (unsplit ? cdiv64(tiles, 2) < 128 : (finished && tiles >= 128))) return {1, 1};
+    if (tiles <= 256 && (unsplit ? cdiv64(tiles, 2) < 128 : (finished && tiles >= 128))) return {1, 1};
     if (finished && !unsplit && cdiv64(tiles, CT) >= 128) return {CT, 1};
     int64_t S = 1;
     if (!unsplit) {

@@ -674,7 +674,7 @@ __global__ __launch_bounds__(64 * WK) void wide2_gemm(Args a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t q = wq[d][t][i], q2 = q >> 8;
-                // plain C, not the asm and_or: hipcc does not pad an asm VALU result that an MFMA reads next (DESIGN.md section 6,
+                // plain C, not the asm and_or: hipcc does not pad an asm VALU result that an MFMA reads next (NOTEBOOK.md section 6,
                 // round 3: stale rows); the same expression in C compiles to v_and_or_b32 with the hazard handled
                 const u32x4 raw = {(q & M0r) | EXr, (q & M1r) | EXH, (q2 & M0r) | EXr, (q2 & M1r) | EXH};
                 if (d == 0 && i == 0)
