@@ -150,3 +150,14 @@ def test_get_indices_to_keep_merge():
     assert Model.get_indices_to_keep(reqs, [3, 8]) == [0, 2, 4]
     assert Model.get_indices_to_keep(reqs, [1, 2, 13, 99]) == [1, 2, 3]
     assert Model.get_indices_to_keep(reqs, []) == [0, 1, 2, 3, 4]
+
+
+def test_decode_graph_buckets():
+    """flash_causal_lm.graph_bucket: which captured decode step serves a batch of B requests (powers of two to 8, then
+    multiples of 8): a batch wandering over 24..32 requests replays two graphs, not nine."""
+    from tgis_amd.models.flash_causal_lm import graph_bucket
+
+    assert [graph_bucket(b) for b in (1, 2, 3, 4, 5, 8, 9, 16, 17, 24, 25, 32, 33, 63, 64, 65)] == \
+        [1, 2, 4, 4, 8, 8, 16, 16, 24, 24, 32, 32, 40, 64, 64, 72]
+    assert all(graph_bucket(b) >= b for b in range(1, 300))
+    assert len({graph_bucket(b) for b in range(24, 33)}) == 2

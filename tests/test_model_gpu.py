@@ -596,3 +596,22 @@ def test_decode_graph_buckets_match_exact_size_graphs(gpu_device, monkeypatch):
         assert [t.token_id for t in tb] == [t.token_id for t in te], f"step {i}: ids"
         assert [t.logprob for t in tb] == [t.logprob for t in te], f"step {i}: logprobs"
         assert np.array_equal(lb, le), f"step {i}: logits differ between the bucket graph and the exact-size graph"
+
+
+def test_bench_churn_mode_runs(gpu_device):
+    """`bench.py --churn` (requests leaving and joining a running batch on pristine and aged page pools, bucketed vs exact-size
+    decode graphs) end to end on the tiny configuration: one JSON line, four runs, no page leaked (the runs assert it)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "llama-tiny-gptq", "--churn", "--churn-steps",
+                        "48"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert [r["run"] for r in d["runs"]] == ["A", "B", "B2", "C"]
+    for r in d["runs"]:
+        assert r["decode_steps"] == 48 and r["p50_ms"] > 0 and r["membership_events"] >= 4
+    assert d["runs"][3]["graph_captures"] >= d["runs"][1]["graph_captures"]
