@@ -625,6 +625,11 @@ extern "C" int tgis_attn_num_splits(int64_t B, int Hkv, int H, int64_t max_q_len
         // (tools/attn_nw.py, us: B=16 GQA 8:1 D=64 ctx 512: 6.8 unsplit vs 8.5 at 4 splits of 4 waves;
         //  B=1 MHA D=128 ctx 2048: 14.1 at 8 splits vs 17.7 at 16; B=4 GQA 4:1 ctx 4096: 19.0 at 8 vs 24.0 at 16)
         ns = std::min<int64_t>(cdiv64(256, base), pages / 16);
+        // Round 6 (profiles/r06_attn_fewgroups.log, first column = the rule above): from 32 pages on, up to 8 splits of >= 8
+        // pages pay as long as every block still gets a CU of its own — B 1 MHA ctx 1024 11.6 -> 9.5 us (2 -> 8 splits), B 4
+        // GQA 8:1 12.3 -> 10.4, B 8 GQA 8:1 D 64 9.4 -> 8.3, B 2 MHA 12.9 -> 11.8; 96 groups keep 2 (3 would be 288 blocks:
+        // 16.4 vs 14.3), 16 pages keep 1 (8.7 vs 10.2), long contexts keep the rule above (>= 16 pages per block).
+        if (pages >= 32) ns = std::max<int64_t>(ns, std::min<int64_t>(std::min<int64_t>(256 / base, pages / 8), 8));
         // From 128 groups on the merge costs more than the second half of the CUs gives while the context is short (a 7B rank at
         // TP = 8, B 32 x 4 heads, ctx 1024: 16.0 us unsplit, 16.5 at 2 splits; 64 groups, ctx 2048: 24.0 / 19.2 / 17.7 at
         // 1 / 2 / 4 — profiles/r05_attn_tp8.log).  Round 6 swept it over the context (profiles/r06_attn_base128.log): exactly
