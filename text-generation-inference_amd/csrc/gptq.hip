@@ -854,6 +854,11 @@ extern "C" int tgis_gptq_gemm_f16(const void* x, int64_t ldx, const void* prepar
 }
 
 // ---- qkv projection with the rotary embedding and the cache write in its epilogue ------------------------------------
+static int64_t rope_min_blocks(int64_t M) {
+    static const int64_t min_blocks = getenv("TGIS_ROPE_MIN_BLOCKS") ? atoll(getenv("TGIS_ROPE_MIN_BLOCKS")) : 128;
+    return M <= 32 ? std::min<int64_t>(min_blocks, 48) : min_blocks;
+}
+
 extern "C" int tgis_gptq_rope_ok(int64_t M, int64_t K, int64_t N, int64_t groups, int act_order, int64_t D) {
     if (M < 1 || M > 64 || act_order || groups <= 0 || K % groups || D < 32 || D % 32 || N <= 0 || N % D) return 0;
     const int64_t gs = K / groups, spg = gs / 64;
@@ -861,10 +866,14 @@ extern "C" int tgis_gptq_rope_ok(int64_t M, int64_t K, int64_t N, int64_t groups
     // The epilogue needs the whole k range in one block (no split-K): worth it only while that plan still covers the chip
     // (measured: 7B qkv at 32 rows, 192 blocks: 14.9 vs 17.2 us for the pair; 70B qkv at 64 rows, 80 blocks of 42 MB: +5 % on
     // the step; a TP = 8 shard of the 7B qkv, 24 blocks: +2 % on the rank-step; TinyLlama dense, 40 blocks: +-0).
+    // Round 6: counted in blocks of the kernel that will run it (the fragment-order kernel gives a wave ONE tile where two would
+    // leave fewer than 128 blocks), and up to 32 rows it pays from 48 blocks on — one rank of cfg3 at TP 8 / 4 / 2 (48 / 96 / 192
+    // one-tile blocks) 1.838 / 2.110 / 3.000 -> 1.815 / 2.072 / 2.903 ms per step; at 64 rows every block takes in twice the
+    // activation and the bar stays at 128 (a cfg4 rank at TP 8, 40 blocks: 6.45 -> 7.10 ms).  profiles/r06_tp_rope_blocks.log
     const GemmPlan pl = plan_gemm(K, N, 2, M);
-    const int64_t blocks = cdiv64(cdiv64(N, 32), pl.TN);
-    static const int64_t min_blocks = getenv("TGIS_ROPE_MIN_BLOCKS") ? atoll(getenv("TGIS_ROPE_MIN_BLOCKS")) : 128;
-    return blocks >= min_blocks ? 1 : 0;
+    const int64_t blocks = gptq::wide_serves(M, K, N, groups, false) ? gptq::wide_blocks(K, N, 3, M)
+                                                                     : cdiv64(cdiv64(N, 32), pl.TN);
+    return blocks >= rope_min_blocks(M) ? 1 : 0;
 }
 
 extern "C" int tgis_gptq_gemm_rope_f16(const void* x, int64_t ldx, const void* prepared, const void* bias,
@@ -910,11 +919,10 @@ extern "C" int tgis_gptq_fragments_ok(int64_t M, int64_t K, int64_t N, int64_t g
     if (off) return 0;
     static const int64_t max_rows = getenv("TGIS_GPTQ_FRAGMENTS_MAX_ROWS") ? atoll(getenv("TGIS_GPTQ_FRAGMENTS_MAX_ROWS")) : 64;
     if (M > max_rows) return 0;
-    static const int64_t min_blocks = getenv("TGIS_ROPE_MIN_BLOCKS") ? atoll(getenv("TGIS_ROPE_MIN_BLOCKS")) : 128;
     // SiLU * up: from 64 blocks on (round 5, a 7B gate_up shard at TP = 8, 86 one-tile blocks: 8.2 us against 6.3 + 4.7 for
     // the split streaming kernel + its reduce, profiles/r05_tp8_variants.log)
     static const int64_t min_blocks_silu = getenv("TGIS_SILU_MIN_BLOCKS") ? atoll(getenv("TGIS_SILU_MIN_BLOCKS")) : 64;
-    if (act == 3 && gptq::wide_blocks(K, N, act, M) < min_blocks) return 0;
+    if (act == 3 && gptq::wide_blocks(K, N, act, M) < rope_min_blocks(M)) return 0;
     if (act == 2 && gptq::wide_blocks(K, N, act, M, true) < min_blocks_silu) return 0;
     return 1;
 }
